@@ -1,0 +1,227 @@
+"""ORACLE -- ctypes binding of oracle/_build/liboracle.so (test infrastructure only).
+
+`OracleVecEnv` steps E independent envs on the CPU in float64 (tier 2: libm, follows the
+reference + restated rps operation for operation) or float32 (tier 3: the spec'd float
+arithmetic the HIP kernels reproduce bit for bit).  See oracle_core.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+MAXN, MAXP = 16, 64
+SCN = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2}
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("scenario", C.c_int32), ("n_agents", C.c_int32), ("obs_dim", C.c_int32),
+        ("update_frequency", C.c_int32), ("controller_period", C.c_int32),
+        ("max_episode_steps", C.c_int32), ("penalize_violations", C.c_int32),
+        ("barrier_has_unsafe_gain", C.c_int32), ("collision_variant", C.c_int32),
+        ("capability_aware", C.c_int32), ("num_prey", C.c_int32), ("num_neighbors", C.c_int32),
+        ("torque", C.c_int32 * MAXN),
+        ("time_step", C.c_double), ("bound_x0", C.c_double), ("bound_y0", C.c_double),
+        ("bound_w", C.c_double), ("bound_h", C.c_double),
+        ("robot_diameter", C.c_double), ("wheel_radius", C.c_double), ("max_linear_velocity", C.c_double),
+        ("collision_offset", C.c_double), ("collision_diameter", C.c_double),
+        ("projection_distance", C.c_double), ("angular_velocity_limit", C.c_double),
+        ("position_velocity_limit", C.c_double),
+        ("barrier_gain", C.c_double), ("unsafe_barrier_gain", C.c_double), ("safety_radius", C.c_double),
+        ("barrier_magnitude_limit", C.c_double),
+        ("left", C.c_double), ("right", C.c_double), ("up", C.c_double), ("down", C.c_double),
+        ("agent_step", C.c_double * MAXN), ("sensing_radius", C.c_double * MAXN),
+        ("capture_radius", C.c_double * MAXN),
+        ("time_penalty", C.c_double), ("sense_reward", C.c_double), ("capture_reward", C.c_double),
+        ("violation_reward", C.c_double),
+        ("load_reward", C.c_double), ("unload_reward", C.c_double), ("goal_width", C.c_double),
+        ("unload_multiplier", C.c_double), ("load_multiplier", C.c_double), ("end_goal_width", C.c_double),
+        ("zone1_radius", C.c_double),
+    ]
+
+
+def build_library(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                              for f in ("oracle.c", "oracle_core.h", "oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_library())
+        assert _lib.orc_sizeof_params() == C.sizeof(OrcParams), "orc_params layout mismatch"
+    return _lib
+
+
+def params_from_config(scenario, cfg, collision_variant="offset"):
+    """YAML keys of the reference's scenario config.yaml -> orc_params (Appendix A/B constants)."""
+    p = OrcParams()
+    p.scenario = SCN[scenario]
+    p.update_frequency = int(cfg["update_frequency"])
+    p.controller_period = 15
+    p.max_episode_steps = int(cfg["max_episode_steps"])
+    p.penalize_violations = int(bool(cfg["penalize_violations"]))
+    bc = cfg.get("barrier_certificate", "safe")   # roboEnv.py:15-18: absent -> Controller() -> 'safe'
+    assert bc in ("safe", "default")
+    p.barrier_has_unsafe_gain = 1 if bc == "safe" else 0
+    p.safety_radius = 0.2 if bc == "safe" else 0.17   # controller.py:13-16
+    p.barrier_gain, p.unsafe_barrier_gain, p.barrier_magnitude_limit = 100.0, 1e6, 0.2
+    p.collision_variant = {"center": 0, "offset": 1}[collision_variant]
+    p.time_step = 0.033
+    p.bound_x0, p.bound_y0, p.bound_w, p.bound_h = -1.6, -1.0, 3.2, 2.0
+    p.robot_diameter, p.wheel_radius, p.max_linear_velocity = 0.11, 0.016, 0.2
+    p.collision_offset, p.collision_diameter = 0.025, 0.135
+    p.projection_distance, p.angular_velocity_limit, p.position_velocity_limit = 0.05, np.pi, 0.15
+    p.left, p.right, p.up, p.down = cfg["LEFT"], cfg["RIGHT"], cfg["UP"], cfg["DOWN"]
+    if scenario == "PredatorCapturePrey":
+        npred, ncap = int(cfg["predator"]), int(cfg["capture"])
+        N = npred + ncap
+        p.n_agents = N
+        p.capability_aware = int(bool(cfg["capability_aware"]))
+        p.num_prey = int(cfg["num_prey"])
+        p.num_neighbors = int(cfg["num_neighbors"])
+        od = 6 if p.capability_aware else 4
+        p.obs_dim = od * (p.num_neighbors + 1)
+        for a in range(N):
+            p.agent_step[a] = cfg["step_dist"]
+            p.sensing_radius[a] = cfg["predator_radius"] if a < npred else 0.0
+            p.capture_radius[a] = 0.0 if a < npred else cfg["capture_radius"]
+        p.time_penalty, p.sense_reward, p.capture_reward = cfg["time_penalty"], cfg["sense_reward"], cfg["capture_reward"]
+        p.violation_reward = -5.0
+    elif scenario == "Warehouse":
+        N = int(cfg["n_agents"])
+        p.n_agents = N
+        p.num_neighbors = int(cfg["num_neighbors"])
+        p.obs_dim = 3 * (p.num_neighbors + 1)
+        for a in range(N):
+            p.agent_step[a] = cfg["step_dist"]
+        p.load_reward, p.unload_reward, p.goal_width = cfg["load_reward"], cfg["unload_reward"], cfg["goal_width"]
+        p.violation_reward = -5.0
+    else:
+        nf, ns = int(cfg["n_fast_agents"]), int(cfg["n_slow_agents"])
+        N = int(cfg["n_agents"])
+        assert nf + ns == N
+        p.n_agents = N
+        p.capability_aware = int(bool(cfg["capability_aware"]))
+        p.obs_dim = 11 if p.capability_aware else 9
+        for a in range(N):
+            p.agent_step[a] = cfg["fast_step"] if a < nf else cfg["slow_step"]
+            p.torque[a] = int(cfg["small_torque"] if a < nf else cfg["large_torque"])
+        p.time_penalty = cfg["time_penalty"]
+        p.unload_multiplier, p.load_multiplier = cfg["unload_multiplier"], cfg["load_multiplier"]
+        p.end_goal_width, p.zone1_radius = cfg["end_goal_width"], cfg["zone1_radius"]
+        p.violation_reward = -6.0
+    return p
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct)) if a is not None else None
+
+
+class OracleVecEnv(object):
+    """E envs, state in numpy arrays of `dtype` (np.float64 or np.float32)."""
+
+    def __init__(self, scenario, cfg, E, dtype=np.float64, collision_variant="offset"):
+        self.scenario, self.cfg, self.E = scenario, dict(cfg), E
+        self.dtype = np.dtype(dtype)
+        assert self.dtype in (np.dtype(np.float64), np.dtype(np.float32))
+        self.p = params_from_config(scenario, cfg, collision_variant)
+        N, P, D = self.p.n_agents, self.p.num_prey, self.p.obs_dim
+        self.N, self.P, self.D = N, P, D
+        f = self.dtype
+        self.poses = np.zeros((E, 3, N), f)
+        self.carry = np.zeros((E, N), f)
+        self.steps = np.zeros(E, np.int32)
+        self.prey_loc = np.zeros((E, max(P, 1), 2), f)
+        self.prey_sensed = np.zeros((E, max(P, 1)), np.uint8)
+        self.prey_captured = np.zeros((E, max(P, 1)), np.uint8)
+        self.loaded = np.zeros((E, N), np.uint8)
+        self.load = np.zeros((E, N), np.int32)
+        self.zone_load = np.zeros((E, 2), np.int32)
+        self.messages = np.zeros((E, 4), np.int32)
+        self.obs = np.zeros((E, N, D), f)
+        self.reward = np.zeros((E, N), f)
+        self.done = np.zeros(E, np.uint8)
+        self.dist = np.zeros((E, N), f)
+        self.viol = np.zeros(E, np.uint8)
+        self.remaining = np.zeros(E, np.int32)
+        self.qp_sweeps = np.zeros(E, np.int32)
+        self._fn = lib().orc_step_f64 if f == np.float64 else lib().orc_step_f32
+        self._fn.restype = C.c_int
+
+    STATE_KEYS = ("poses", "carry", "steps", "prey_loc", "prey_sensed", "prey_captured", "loaded", "load",
+                  "zone_load", "messages")
+
+    def set_state(self, e, **kw):
+        for k, v in kw.items():
+            arr = getattr(self, k)
+            arr[e] = np.asarray(v).astype(arr.dtype)
+
+    def get_state(self, e):
+        return {k: getattr(self, k)[e].copy() for k in self.STATE_KEYS}
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.E, self.N)
+        ct = C.c_double if self.dtype == np.float64 else C.c_float
+
+        class St(C.Structure):
+            _fields_ = [("poses", C.POINTER(ct)), ("carry", C.POINTER(ct)), ("steps", C.POINTER(C.c_int32)),
+                        ("prey_loc", C.POINTER(ct)), ("prey_sensed", C.POINTER(C.c_uint8)),
+                        ("prey_captured", C.POINTER(C.c_uint8)), ("loaded", C.POINTER(C.c_uint8)),
+                        ("load", C.POINTER(C.c_int32)), ("zone_load", C.POINTER(C.c_int32)),
+                        ("messages", C.POINTER(C.c_int32))]
+
+        class Out(C.Structure):
+            _fields_ = [("obs", C.POINTER(ct)), ("reward", C.POINTER(ct)), ("done", C.POINTER(C.c_uint8)),
+                        ("dist", C.POINTER(ct)), ("viol", C.POINTER(C.c_uint8)),
+                        ("remaining", C.POINTER(C.c_int32)), ("qp_sweeps", C.POINTER(C.c_int32))]
+
+        st = St(_ptr(self.poses, ct), _ptr(self.carry, ct), _ptr(self.steps, C.c_int32), _ptr(self.prey_loc, ct),
+                _ptr(self.prey_sensed, C.c_uint8), _ptr(self.prey_captured, C.c_uint8), _ptr(self.loaded, C.c_uint8),
+                _ptr(self.load, C.c_int32), _ptr(self.zone_load, C.c_int32), _ptr(self.messages, C.c_int32))
+        out = Out(_ptr(self.obs, ct), _ptr(self.reward, ct), _ptr(self.done, C.c_uint8), _ptr(self.dist, ct),
+                  _ptr(self.viol, C.c_uint8), _ptr(self.remaining, C.c_int32), _ptr(self.qp_sweeps, C.c_int32))
+        rc = self._fn(C.byref(self.p), C.c_int(self.E), C.byref(st), _ptr(actions, C.c_int32), C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"orc_step failed: {rc}")
+        return self.obs, self.reward, self.done, {"dist_travelled": self.dist, "violation": self.viol,
+                                                  "remaining": self.remaining}
+
+
+def spec_sincos_f32(t):
+    t = np.ascontiguousarray(t, np.float32)
+    s, c = np.empty_like(t), np.empty_like(t)
+    lib().orc_sincos_f32(C.c_int(t.size), _ptr(t, C.c_float), _ptr(s, C.c_float), _ptr(c, C.c_float))
+    return s, c
+
+
+def spec_atan2_f32(y, x):
+    y = np.ascontiguousarray(y, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    o = np.empty_like(y)
+    lib().orc_atan2_f32(C.c_int(y.size), _ptr(y, C.c_float), _ptr(x, C.c_float), _ptr(o, C.c_float))
+    return o
+
+
+def controller(scenario, cfg, poses, goals, dtype=np.float64, collision_variant="offset"):
+    """a3-a8 for one env: poses 3xN, goals 2xN -> (dxu 2xN after set_velocities clipping, sweeps)."""
+    p = params_from_config(scenario, cfg, collision_variant)
+    f = np.dtype(dtype)
+    ct = C.c_double if f == np.float64 else C.c_float
+    poses = np.ascontiguousarray(poses, f)
+    goals = np.ascontiguousarray(goals[:2], f)
+    p.n_agents = poses.shape[1]
+    dxu = np.zeros((2, poses.shape[1]), f)
+    fn = lib().orc_controller_f64 if f == np.float64 else lib().orc_controller_f32
+    fn.restype = C.c_int
+    sweeps = fn(C.byref(p), _ptr(poses, ct), _ptr(goals, ct), _ptr(dxu, ct))
+    return dxu, sweeps

@@ -1,0 +1,42 @@
+/* ORACLE -- test infrastructure only (see oracle_core.h).  Parameter block of sim_spec_v0. */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+
+#define ORC_MAXN 16
+#define ORC_MAXP 64
+#define ORC_SCN_PCP 0
+#define ORC_SCN_WAREHOUSE 1
+#define ORC_SCN_MT 2
+
+typedef struct orc_params {
+    int32_t scenario;
+    int32_t n_agents;
+    int32_t obs_dim;              /* per-agent observation length D */
+    int32_t update_frequency;     /* U: sim sub-iterations per env step */
+    int32_t controller_period;    /* 15 (roboEnv.py:63) */
+    int32_t max_episode_steps;
+    int32_t penalize_violations;
+    int32_t barrier_has_unsafe_gain; /* 1: certificate2 ('safe'), 0: certificate ('default') */
+    int32_t collision_variant;    /* 0 centre distance <= robot_diameter, 1 offset points <= collision_diameter */
+    int32_t capability_aware;
+    int32_t num_prey;
+    int32_t num_neighbors;
+    int32_t torque[ORC_MAXN];
+    /* rps constants */
+    double time_step, bound_x0, bound_y0, bound_w, bound_h;
+    double robot_diameter, wheel_radius, max_linear_velocity;
+    double collision_offset, collision_diameter;
+    double projection_distance, angular_velocity_limit, position_velocity_limit;
+    double barrier_gain, unsafe_barrier_gain, safety_radius, barrier_magnitude_limit;
+    /* scenario */
+    double left, right, up, down;
+    double agent_step[ORC_MAXN];      /* step_dist, or MaterialTransport per-agent speed */
+    double sensing_radius[ORC_MAXN];
+    double capture_radius[ORC_MAXN];
+    double time_penalty, sense_reward, capture_reward, violation_reward;
+    double load_reward, unload_reward, goal_width;
+    double unload_multiplier, load_multiplier, end_goal_width, zone1_radius;
+} orc_params;
+
+#endif

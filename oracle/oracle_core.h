@@ -1,0 +1,599 @@
+/* ORACLE -- test infrastructure only.  Never linked, imported or executed by marbler_amd/.
+ *
+ * CPU restatement ("sim_spec_v0") of the one hot path this repo accelerates: one
+ * Robotarium-gym env step = goal generation -> U sim sub-iterations {controller every 15th:
+ * uni->si, position controller, barrier-certificate QP, si->uni; validation; Euler
+ * integration} -> scenario tracking / observation / reward / termination.
+ *
+ * This file is included twice by oracle.c: once with REAL=double and libm (tier 2: follows
+ * the reference + rps operation for operation, checked against tests/golden/), once with
+ * REAL=float and the spec'd polynomial sin/cos/atan2 (tier 3: the bit-exact twin of the HIP
+ * kernels, which implement the same arithmetic in the same order on lane groups).
+ *
+ * The arithmetic below the reference's own layers lives in the third-party package rps
+ * (robotarium_python_simulator, pinned by prose to commit 6bb184e, README.md:11) and cvxopt,
+ * both absent from /root/reference and from this image: rows a4-a10 are restated from the
+ * spec in SURVEY.md Appendix A and are PARITY UNPINNED against real rps + cvxopt.  Rows a1,
+ * a2, a11-a16 are pinned by tests/golden/ npz files (captured from the reference's own Python).
+ *
+ * Reference citations are relative to /root/reference/robotarium_gym/.
+ */
+
+#ifndef REAL
+#error "include from oracle.c"
+#endif
+
+/* ---------------------------------------------------------------- math per precision */
+#if ORC_IS_F32
+/* sim_spec_v0 float math: every operation is an IEEE-754 binary32 +,-,*,/,sqrt or an explicit
+ * fma; no contraction (compile with -ffp-contract=off).  The HIP kernels use the same
+ * sequence, so results are bit-identical. */
+static inline void FN(sincos)(float t, float *s, float *c) {
+    float q = rintf(t * 0.63661977236758134f);
+    float r = __builtin_fmaf(q, -1.57079625129699707031f, t);     /* pi/2 hi */
+    r = __builtin_fmaf(q, -7.54978941586159635335e-08f, r);       /* pi/2 lo */
+    float z = r * r;
+    float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(z, sp, -1.6666654611e-1f);
+    float sr = __builtin_fmaf(r * z, sp, r);
+    float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
+    float cr = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
+    int k = ((int)q) & 3;
+    float ss = (k & 1) ? cr : sr;
+    float cc = (k & 1) ? sr : cr;
+    if (k == 1 || k == 2) cc = -cc;
+    if (k >= 2) ss = -ss;
+    *s = ss;
+    *c = cc;
+}
+static inline float FN(atan2)(float y, float x) {
+    float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    float a;
+    if (mx == 0.0f) {
+        a = 0.0f;
+    } else {
+        /* atan(mn/mx) on [0,1]; above tan(pi/8) use atan(t) = pi/4 + atan((t-1)/(t+1)) */
+        int hi = mn > 0.4142135679721832275390625f * mx;
+        float num = hi ? (mn - mx) : mn;
+        float den = hi ? (mn + mx) : mx;
+        float t = num / den;
+        float z = t * t;
+        float p = __builtin_fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+        p = __builtin_fmaf(z, p, 1.99777106478e-1f);
+        p = __builtin_fmaf(z, p, -3.33329491539e-1f);
+        a = __builtin_fmaf(p * z, t, t);
+        if (hi) a = a + 0.785398185253143310546875f;
+    }
+    if (ay > ax) a = 1.57079637050628662109375f - a;
+    if (x < 0.0f) a = 3.1415927410125732421875f - a;
+    return (y < 0.0f) ? -a : a;
+}
+#define SINCOS(t, s, c) FN(sincos)((t), (s), (c))
+#define ATAN2(y, x) FN(atan2)((y), (x))
+#define SQRT(v) __builtin_sqrtf(v)
+#define QP_RTOL 1.25e-6f
+#define QP_MAX_SWEEPS 40
+#else
+#define SINCOS(t, s, c) do { *(s) = sin(t); *(c) = cos(t); } while (0)
+#define ATAN2(y, x) atan2((y), (x))
+#define SQRT(v) sqrt(v)
+#define QP_RTOL 5e-12
+#define QP_MAX_SWEEPS 200
+#endif
+
+#define R(v) ((REAL)(v))
+
+typedef struct {
+    REAL *poses;            /* [E][3][N]  (x row, y row, theta row: the reference's 3xN, roboEnv.py:54) */
+    REAL *carry;            /* [E][N] movement of the last sub-iteration of the previous step, not yet
+                               counted in dist_travelled (roboEnv.py:55-59: previous_pose lags one iteration) */
+    int32_t *steps;         /* [E] episode_steps */
+    REAL *prey_loc;         /* [E][P][2]  PCP */
+    uint8_t *prey_sensed;   /* [E][P] */
+    uint8_t *prey_captured; /* [E][P] */
+    uint8_t *loaded;        /* [E][N]     Warehouse */
+    int32_t *load;          /* [E][N]     MaterialTransport */
+    int32_t *zone_load;     /* [E][2] */
+    int32_t *messages;      /* [E][4] */
+} FN(orc_state);
+
+typedef struct {
+    REAL *obs;          /* [E][N][D] */
+    REAL *reward;       /* [E][N] */
+    uint8_t *done;      /* [E] */
+    REAL *dist;         /* [E][N] */
+    uint8_t *viol;      /* [E] 0 '', 1 collision, 2 boundary, 3 collision_boundary */
+    int32_t *remaining; /* [E] -1 when the reference's info has no 'remaining' */
+    int32_t *qp_sweeps; /* [E] max sweeps of any QP of this step (diagnostic), may be NULL */
+} FN(orc_out);
+
+static inline REAL FN(clampv)(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* a6: barrier certificate as an exact projection (Hildreth sweeps in XOR-factorisation order) */
+static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REAL *xiy, REAL *ux, REAL *uy) {
+    int gw = 2;
+    while (gw < N) gw *= 2;
+    REAL r2 = R(p->safety_radius) * R(p->safety_radius);
+    REAL ex[ORC_MAXN][ORC_MAXN], ey[ORC_MAXN][ORC_MAXN], beta[ORC_MAXN][ORC_MAXN], n2[ORC_MAXN][ORC_MAXN],
+        mu[ORC_MAXN][ORC_MAXN];
+    for (int i = 0; i < N; ++i)
+        for (int j = i + 1; j < N; ++j) {
+            REAL dx = xix[i] - xix[j], dy = xiy[i] - xiy[j];
+            REAL ee = dx * dx + dy * dy;
+            REAL h = ee - r2;
+            REAL gain = (h >= R(0) || !p->barrier_has_unsafe_gain) ? R(p->barrier_gain) : R(p->unsafe_barrier_gain);
+            REAL b = gain * ((h * h) * h);
+            ex[i][j] = dx;
+            ey[i][j] = dy;
+            beta[i][j] = R(0.5) * b;
+            n2[i][j] = R(2) * ee;
+            mu[i][j] = R(0);
+        }
+    /* "Threshold control inputs before QP" */
+    for (int a = 0; a < N; ++a) {
+        REAL nrm = SQRT(ux[a] * ux[a] + uy[a] * uy[a]);
+        if (nrm > R(p->barrier_magnitude_limit)) {
+            REAL sc = R(p->barrier_magnitude_limit) / nrm;
+            ux[a] = ux[a] * sc;
+            uy[a] = uy[a] * sc;
+        }
+    }
+    int sweeps = 0;
+    for (;;) {
+        REAL maxchg = R(0);
+        for (int k = 1; k < gw; ++k)
+            for (int i = 0; i < N; ++i) {
+                int j = i ^ k;
+                if (!(i < j && j < N)) continue;
+                if (!(n2[i][j] > R(0))) continue;
+                REAL r = ex[i][j] * (ux[j] - ux[i]) + ey[i][j] * (uy[j] - uy[i]) - beta[i][j];
+                REAL d = r / n2[i][j];
+                REAL mn = mu[i][j] + d;
+                if (!(mn > R(0))) mn = R(0);
+                REAL delta = mn - mu[i][j];
+                mu[i][j] = mn;
+                REAL cx = delta * ex[i][j], cy = delta * ey[i][j];
+                ux[i] = ux[i] + cx;
+                uy[i] = uy[i] + cy;
+                ux[j] = ux[j] - cx;
+                uy[j] = uy[j] - cy;
+                REAL acx = cx < R(0) ? -cx : cx, acy = cy < R(0) ? -cy : cy;
+                if (acx > maxchg) maxchg = acx;
+                if (acy > maxchg) maxchg = acy;
+            }
+        ++sweeps;
+        /* converged when the largest component change of the sweep is below QP_RTOL relative to
+         * max(|u|_inf, magnitude_limit) */
+        REAL umax = R(p->barrier_magnitude_limit);
+        for (int a = 0; a < N; ++a) {
+            REAL ax = ux[a] < R(0) ? -ux[a] : ux[a], ay = uy[a] < R(0) ? -uy[a] : uy[a];
+            if (ax > umax) umax = ax;
+            if (ay > umax) umax = ay;
+        }
+        if (!(maxchg > QP_RTOL * umax) || sweeps >= QP_MAX_SWEEPS) break;
+    }
+    return sweeps;
+}
+
+/* a3 = a4 . a5 . a6 . a7, then a8 (utilities/controller.py:20-24, roboEnv.py:64-65) */
+static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *th, const REAL *gx,
+                          const REAL *gy, REAL *v, REAL *w) {
+    REAL cs[ORC_MAXN], ss[ORC_MAXN], xix[ORC_MAXN], xiy[ORC_MAXN], ux[ORC_MAXN], uy[ORC_MAXN];
+    REAL pd = R(p->projection_distance);
+    for (int a = 0; a < N; ++a) {
+        SINCOS(th[a], &ss[a], &cs[a]);
+        xix[a] = x[a] + pd * cs[a]; /* a4 uni_to_si_states */
+        xiy[a] = y[a] + pd * ss[a];
+        REAL dx = gx[a] - xix[a], dy = gy[a] - xiy[a]; /* a5 si_position_controller, gain 1 */
+        REAL nrm = SQRT(dx * dx + dy * dy);
+        if (nrm > R(p->position_velocity_limit)) {
+            REAL sc = R(p->position_velocity_limit) / nrm;
+            dx = dx * sc;
+            dy = dy * sc;
+        }
+        ux[a] = dx;
+        uy[a] = dy;
+    }
+    int sweeps = FN(barrier_qp)(p, N, xix, xiy, ux, uy); /* a6 */
+    REAL inv_pd = R(1) / pd;
+    REAL wlim = R(p->angular_velocity_limit);
+    REAL vmax = R(p->max_linear_velocity);
+    REAL wmax = R(2) * (R(p->wheel_radius) / R(p->robot_diameter)) * (vmax / R(p->wheel_radius));
+    for (int a = 0; a < N; ++a) { /* a7 si_to_uni_dyn, a8 set_velocities */
+        REAL vv = cs[a] * ux[a] + ss[a] * uy[a];
+        REAL ww = inv_pd * (-ss[a] * ux[a] + cs[a] * uy[a]);
+        if (ww > wlim) ww = wlim;
+        if (ww < -wlim) ww = -wlim;
+        if (vv > vmax) vv = vmax;
+        if (vv < -vmax) vv = -vmax;
+        if (ww > wmax) ww = wmax;
+        if (ww < -wmax) ww = -wmax;
+        v[a] = vv;
+        w[a] = ww;
+    }
+    return sweeps;
+}
+
+/* a10 _validate: returns bit0 collision, bit1 boundary */
+static int FN(validate)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *th) {
+    int code = 0;
+    REAL xmin = R(p->bound_x0), ymin = R(p->bound_y0);
+    REAL xmax = xmin + R(p->bound_w), ymax = ymin + R(p->bound_h);
+    for (int a = 0; a < N; ++a)
+        if (x[a] < xmin || x[a] > xmax || y[a] < ymin || y[a] > ymax) code |= 2;
+    REAL fx[ORC_MAXN], fy[ORC_MAXN];
+    REAL lim;
+    if (p->collision_variant == 1) {
+        for (int a = 0; a < N; ++a) {
+            REAL s, c;
+            SINCOS(th[a], &s, &c);
+            fx[a] = x[a] + R(p->collision_offset) * c;
+            fy[a] = y[a] + R(p->collision_offset) * s;
+        }
+        lim = R(p->collision_diameter);
+    } else {
+        for (int a = 0; a < N; ++a) {
+            fx[a] = x[a];
+            fy[a] = y[a];
+        }
+        lim = R(p->robot_diameter);
+    }
+    for (int j = 0; j < N - 1; ++j)
+        for (int k = j + 1; k < N; ++k) {
+            REAL dx = fx[j] - fx[k], dy = fy[j] - fy[k];
+            if (SQRT(dx * dx + dy * dy) <= lim) code |= 1;
+        }
+    return code;
+}
+
+/* neighbours of agent a: K nearest, ascending distance, ties -> lower index (the canonical
+ * order; misc.py:20-25 leaves it to np.argpartition).  K >= N-1: all others in index order. */
+static int FN(neighbours)(int N, int K, int a, const REAL *x, const REAL *y, int *out) {
+    if (K >= N - 1) {
+        int n = 0;
+        for (int j = 0; j < N; ++j)
+            if (j != a) out[n++] = j;
+        return n;
+    }
+    REAL d[ORC_MAXN];
+    for (int j = 0; j < N; ++j) {
+        REAL dx = x[j] - x[a], dy = y[j] - y[a];
+        d[j] = SQRT(dx * dx + dy * dy);
+    }
+    for (int j = 0; j < N; ++j) {
+        if (j == a) continue;
+        int rank = 0;
+        for (int k = 0; k < N; ++k) {
+            if (k == a || k == j) continue;
+            if (d[k] < d[j] || (d[k] == d[j] && k < j)) ++rank;
+        }
+        if (rank < K) out[rank] = j;
+    }
+    return K;
+}
+
+static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, const int32_t *actions,
+                         const FN(orc_out) * out) {
+    const int N = p->n_agents;
+    REAL *X = st->poses + (size_t)e * 3 * N, *Y = X + N, *TH = Y + N;
+    REAL x[ORC_MAXN], y[ORC_MAXN], th[ORC_MAXN], gx[ORC_MAXN], gy[ORC_MAXN], px[ORC_MAXN], py[ORC_MAXN];
+    REAL v[ORC_MAXN], w[ORC_MAXN], dist[ORC_MAXN];
+    const int32_t *act = actions + (size_t)e * N;
+    REAL L = R(p->left), Rt = R(p->right), Up = R(p->up), Dn = R(p->down);
+    for (int a = 0; a < N; ++a) {
+        x[a] = X[a];
+        y[a] = Y[a];
+        th[a] = TH[a];
+        v[a] = R(0);
+        w[a] = R(0);
+        dist[a] = R(0);
+        px[a] = x[a];
+        py[a] = y[a];
+        /* a1 generate_goal (PCP agent.py:48-76, warehouse.py:19-45, MaterialTransport.py:19-46) */
+        int mv = (p->scenario == ORC_SCN_MT) ? act[a] / 4 : act[a];
+        REAL sd = R(p->agent_step[a]);
+        REAL tx = x[a], ty = y[a];
+        if (mv == 0) {
+            REAL t = tx - sd;
+            tx = t > L ? t : L;
+            ty = FN(clampv)(ty, Up, Dn);
+        } else if (mv == 1) {
+            REAL t = tx + sd;
+            tx = t < Rt ? t : Rt;
+            ty = FN(clampv)(ty, Up, Dn);
+        } else if (mv == 2) {
+            tx = FN(clampv)(tx, L, Rt);
+            REAL t = ty - sd;
+            ty = t > Up ? t : Up;
+        } else if (mv == 3) {
+            tx = FN(clampv)(tx, L, Rt);
+            REAL t = ty + sd;
+            ty = t < Dn ? t : Dn;
+        } else {
+            tx = FN(clampv)(tx, L, Rt);
+            ty = FN(clampv)(ty, Up, Dn);
+        }
+        gx[a] = tx;
+        gy[a] = ty;
+    }
+    /* a2 roboEnv.step (utilities/roboEnv.py:38-96) */
+    int viol = 0, max_sweeps = 0;
+    REAL dt = R(p->time_step);
+    for (int it = 0; it < p->update_frequency; ++it) {
+        for (int a = 0; a < N; ++a) {
+            if (it == 0) {
+                dist[a] = dist[a] + st->carry[(size_t)e * N + a];
+            } else {
+                REAL dx = x[a] - px[a], dy = y[a] - py[a];
+                dist[a] = dist[a] + SQRT(dx * dx + dy * dy);
+            }
+            px[a] = x[a];
+            py[a] = y[a];
+        }
+        if (it % p->controller_period == 0) {
+            int s = FN(controller)(p, N, x, y, th, gx, gy, v, w);
+            if (s > max_sweeps) max_sweeps = s;
+        }
+        int code = FN(validate)(p, N, x, y, th); /* rps step(): validate first ... */
+        for (int a = 0; a < N; ++a) {            /* ... then Euler + wrap (Appendix A.4) */
+            REAL s, c;
+            SINCOS(th[a], &s, &c);
+            x[a] = x[a] + dt * c * v[a];
+            y[a] = y[a] + dt * s * v[a];
+            REAL t = th[a] + dt * w[a];
+            REAL s2, c2;
+            SINCOS(t, &s2, &c2);
+            th[a] = ATAN2(s2, c2);
+        }
+        if (p->penalize_violations && code) { /* roboEnv.py:82-94 */
+            viol = code;
+            for (int a = 0; a < N; ++a) {
+                REAL dx = x[a] - px[a], dy = y[a] - py[a];
+                dist[a] = dist[a] + SQRT(dx * dx + dy * dy);
+            }
+            break;
+        }
+    }
+    for (int a = 0; a < N; ++a) {
+        X[a] = x[a];
+        Y[a] = y[a];
+        TH[a] = th[a];
+        REAL dx = x[a] - px[a], dy = y[a] - py[a];
+        st->carry[(size_t)e * N + a] = SQRT(dx * dx + dy * dy);
+        out->dist[(size_t)e * N + a] = dist[a];
+    }
+    out->viol[e] = (uint8_t)viol;
+    if (out->qp_sweeps) out->qp_sweeps[e] = max_sweeps;
+    int steps = st->steps[e] + 1;
+    st->steps[e] = steps;
+    const int D = p->obs_dim;
+    REAL *obs = out->obs + (size_t)e * N * D;
+    REAL *rew = out->reward + (size_t)e * N;
+    int done = 0, remaining = -1;
+
+    if (p->scenario == ORC_SCN_PCP) {
+        const int P = p->num_prey;
+        REAL *pl = st->prey_loc + (size_t)e * P * 2;
+        uint8_t *sensed = st->prey_sensed + (size_t)e * P, *captured = st->prey_captured + (size_t)e * P;
+        int unseen0 = 0, left0 = 0;
+        for (int i = 0; i < P; ++i) {
+            unseen0 += !sensed[i];
+            left0 += !captured[i];
+        }
+        REAL dpa[ORC_MAXP][ORC_MAXN];
+        for (int i = 0; i < P; ++i)
+            for (int a = 0; a < N; ++a) {
+                REAL dx = x[a] - pl[2 * i], dy = y[a] - pl[2 * i + 1];
+                dpa[i][a] = SQRT(dx * dx + dy * dy);
+            }
+        /* a11 _update_tracking_and_locations (PredatorCapturePrey.py:72-95) */
+        for (int i = 0; i < P; ++i) {
+            if (captured[i]) continue;
+            if (!sensed[i])
+                for (int a = 0; a < N; ++a)
+                    if (dpa[i][a] <= R(p->sensing_radius[a])) {
+                        sensed[i] = 1;
+                        break;
+                    }
+            if (sensed[i])
+                for (int a = 0; a < N; ++a)
+                    if (act[a] == 4 && dpa[i][a] <= R(p->capture_radius[a])) {
+                        captured[i] = 1;
+                        break;
+                    }
+        }
+        int unseen1 = 0, left1 = 0; /* a12 */
+        for (int i = 0; i < P; ++i) {
+            unseen1 += !sensed[i];
+            left1 += !captured[i];
+        }
+        /* a13 observations (agent.py:19-46, PredatorCapturePrey.py:178-207) */
+        const int od = p->capability_aware ? 6 : 4;
+        REAL own[ORC_MAXN][6];
+        for (int a = 0; a < N; ++a) {
+            REAL closest = R(-1), qx = R(-5), qy = R(-5);
+            for (int i = 0; i < P; ++i) {
+                if (captured[i]) continue;
+                REAL d = dpa[i][a];
+                if (d <= R(p->sensing_radius[a]) && (d < closest || closest == R(-1))) {
+                    qx = pl[2 * i];
+                    qy = pl[2 * i + 1];
+                    closest = d;
+                }
+            }
+            own[a][0] = x[a];
+            own[a][1] = y[a];
+            own[a][2] = qx;
+            own[a][3] = qy;
+            own[a][4] = R(p->sensing_radius[a]);
+            own[a][5] = R(p->capture_radius[a]);
+        }
+        for (int a = 0; a < N; ++a) {
+            int nb[ORC_MAXN];
+            int nn = FN(neighbours)(N, p->num_neighbors, a, x, y, nb);
+            REAL *o = obs + (size_t)a * D;
+            for (int c = 0; c < od; ++c) o[c] = own[a][c];
+            for (int m = 0; m < nn; ++m)
+                for (int c = 0; c < od; ++c) o[(m + 1) * od + c] = own[nb[m]][c];
+        }
+        /* a14 reward / termination (PredatorCapturePrey.py:155-176, 209-216) */
+        REAL r;
+        if (viol) {
+            r = R(p->violation_reward);
+            done = 1;
+        } else {
+            r = R(0);
+            r = r + (REAL)(unseen0 - unseen1) * R(p->sense_reward);
+            r = r + (REAL)(left0 - left1) * R(p->capture_reward);
+            r = r + R(p->time_penalty);
+            if (steps > p->max_episode_steps || left1 == 0) {
+                done = 1;
+                remaining = left1;
+            }
+        }
+        for (int a = 0; a < N; ++a) rew[a] = r;
+    } else if (p->scenario == ORC_SCN_WAREHOUSE) {
+        /* a15 (warehouse.py:124-143 obs BEFORE the reward mutates `loaded`, :145-178, :102-122) */
+        uint8_t *loaded = st->loaded + (size_t)e * N;
+        REAL own[ORC_MAXN][3];
+        for (int a = 0; a < N; ++a) {
+            own[a][0] = x[a];
+            own[a][1] = y[a];
+            own[a][2] = loaded[a] ? R(1) : R(0);
+        }
+        for (int a = 0; a < N; ++a) {
+            int nb[ORC_MAXN];
+            int nn = FN(neighbours)(N, p->num_neighbors, a, x, y, nb);
+            REAL *o = obs + (size_t)a * D;
+            for (int c = 0; c < 3; ++c) o[c] = own[a][c];
+            for (int m = 0; m < nn; ++m)
+                for (int c = 0; c < 3; ++c) o[(m + 1) * 3 + c] = own[nb[m]][c];
+        }
+        if (viol) {
+            for (int a = 0; a < N; ++a) rew[a] = R(p->violation_reward);
+            done = 1;
+        } else {
+            REAL gw_ = R(p->goal_width);
+            for (int a = 0; a < N; ++a) {
+                int green = (a % 2 == 0);
+                REAL r = R(0);
+                if (loaded[a]) {
+                    if (x[a] < R(-1.5) + gw_) {
+                        if ((green && y[a] > R(0)) || (!green && y[a] <= R(0))) {
+                            r = R(p->unload_reward);
+                            loaded[a] = 0;
+                        }
+                    }
+                } else {
+                    if (x[a] > R(1.5) - gw_) {
+                        if ((!green && y[a] > R(0)) || (green && y[a] <= R(0))) {
+                            r = R(p->load_reward);
+                            loaded[a] = 1;
+                        }
+                    }
+                }
+                rew[a] = r;
+            }
+            done = steps > p->max_episode_steps;
+        }
+    } else { /* ORC_SCN_MT */
+        /* a16 (MaterialTransport.py:113-189) */
+        int32_t *load = st->load + (size_t)e * N, *zone = st->zone_load + (size_t)e * 2, *msg = st->messages + (size_t)e * 4;
+        for (int i = 0; i < 4 && i < N; ++i) msg[i] = act[i] % 4;
+        for (int a = 0; a < N; ++a) {
+            REAL *o = obs + (size_t)a * D;
+            o[0] = x[a];
+            o[1] = y[a];
+            o[2] = (REAL)load[a];
+            o[3] = (REAL)zone[0];
+            o[4] = (REAL)zone[1];
+            for (int i = 0; i < 4; ++i) o[5 + i] = (REAL)msg[i];
+            if (p->capability_aware) {
+                o[9] = (REAL)p->torque[a];
+                o[10] = R(p->agent_step[a]);
+            }
+        }
+        REAL r;
+        if (viol) {
+            r = R(p->violation_reward);
+            done = 1;
+        } else {
+            r = R(p->time_penalty);
+            REAL egw = R(p->end_goal_width);
+            for (int a = 0; a < N; ++a) {
+                if (load[a] > 0) {
+                    if (x[a] < R(-1.5) + egw) {
+                        r = r + (REAL)load[a] * R(p->unload_multiplier);
+                        load[a] = 0;
+                    }
+                } else {
+                    if (x[a] > R(1.5) - egw) {
+                        if (zone[1] > p->torque[a]) {
+                            load[a] = p->torque[a];
+                            zone[1] -= p->torque[a];
+                        } else {
+                            load[a] = zone[1];
+                            zone[1] = 0;
+                        }
+                        r = r + (REAL)load[a] * R(p->load_multiplier);
+                    } else if (SQRT(x[a] * x[a] + y[a] * y[a]) <= R(p->zone1_radius)) {
+                        if (zone[0] > p->torque[a]) {
+                            load[a] = p->torque[a];
+                            zone[0] -= p->torque[a];
+                        } else {
+                            load[a] = zone[0];
+                            zone[0] = 0;
+                        }
+                        r = r + (REAL)load[a] * R(p->load_multiplier);
+                    }
+                }
+            }
+            done = steps > p->max_episode_steps;
+            if (!done) {
+                done = (zone[0] == 0 && zone[1] == 0);
+                if (done)
+                    for (int a = 0; a < N; ++a)
+                        if (load[a] != 0) {
+                            done = 0;
+                            break;
+                        }
+            }
+        }
+        if (done) {
+            remaining = zone[0] + zone[1];
+            for (int a = 0; a < N; ++a) remaining += load[a];
+        }
+        for (int a = 0; a < N; ++a) rew[a] = r;
+    }
+    out->done[e] = (uint8_t)done;
+    out->remaining[e] = remaining;
+}
+
+int FN(orc_step)(const orc_params *p, int E, const FN(orc_state) * st, const int32_t *actions, const FN(orc_out) * out) {
+    if (p->n_agents < 1 || p->n_agents > ORC_MAXN) return -1;
+    if (p->scenario == ORC_SCN_PCP && (p->num_prey < 0 || p->num_prey > ORC_MAXP)) return -2;
+    for (int e = 0; e < E; ++e) FN(step_env)(p, e, st, actions, out);
+    return 0;
+}
+
+/* standalone entry points for unit tests of the spec'd pieces */
+void FN(orc_sincos)(int n, const REAL *t, REAL *s, REAL *c) {
+    for (int i = 0; i < n; ++i) SINCOS(t[i], &s[i], &c[i]);
+}
+void FN(orc_atan2)(int n, const REAL *y, const REAL *x, REAL *o) {
+    for (int i = 0; i < n; ++i) o[i] = ATAN2(y[i], x[i]);
+}
+int FN(orc_controller)(const orc_params *p, const REAL *poses /*3xN*/, const REAL *goals /*2xN*/, REAL *dxu /*2xN*/) {
+    int N = p->n_agents;
+    return FN(controller)(p, N, poses, poses + N, poses + 2 * N, goals, goals + N, dxu, dxu + N);
+}
+
+#undef SINCOS
+#undef ATAN2
+#undef SQRT
+#undef QP_RTOL
+#undef QP_MAX_SWEEPS
+#undef R

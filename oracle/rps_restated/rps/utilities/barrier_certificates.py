@@ -1,0 +1,104 @@
+"""ORACLE -- restated `rps.utilities.barrier_certificates` (parity vs real rps + cvxopt unpinned).
+
+Spec: SURVEY.md Appendix A.6.  Reference call sites: utilities/controller.py:2,13-16,23.
+
+Upstream builds  min ||u - dxi||^2  s.t.  -2 e_ij.u_i + 2 e_ij.u_j <= gamma * h_ij^3
+and hands it to cvxopt's interior-point `qp` at loose tolerances (reltol 1e-2), so its
+answer is an approximate iterate no other solver reproduces.  cvxopt is absent here, so
+sim_spec_v0 defines the EXACT projection, computed by Hildreth's dual coordinate ascent
+in a fixed constraint order (the order the HIP kernel can run pair-parallel: the XOR
+1-factorisation of the lane group).  `solve_pair_qp` below is the float64 statement of
+that spec; tests/test_qp.py checks it against an independent active-set solution
+(scipy NNLS / Lawson-Hanson LDP).
+"""
+import numpy as np
+from rps.utilities.transformations import *   # upstream star-imports these; controller.py relies on it
+
+QP_RTOL_F64 = 5e-12
+QP_MAX_SWEEPS_F64 = 200
+
+
+def group_width(N):
+    gw = 2
+    while gw < N:
+        gw *= 2
+    return gw
+
+
+def pair_order(N):
+    """Constraint order of sim_spec_v0: for k = 1..GW-1, pairs (a, a^k) with a < a^k < N."""
+    gw = group_width(N)
+    order = []
+    for k in range(1, gw):
+        for a in range(N):
+            p = a ^ k
+            if a < p < N:
+                order.append((a, p))
+    return order
+
+
+def solve_pair_qp(uhat, x, beta, rtol=QP_RTOL_F64, max_sweeps=QP_MAX_SWEEPS_F64, magnitude_limit=0.2):
+    """Projection of uhat (2xN) onto { u : e_ij.(u_j - u_i) <= beta_ij for all i<j },
+    e_ij = x_i - x_j.  (Upstream's row  -2e.u_i + 2e.u_j <= b  divided by two; beta = b/2.)
+    beta is a dict {(i,j): value}.  Returns (u, sweeps)."""
+    N = uhat.shape[1]
+    u = uhat.copy()
+    order = pair_order(N)
+    mu = {pr: 0.0 for pr in order}
+    sweeps = 0
+    while True:
+        maxchg = 0.0
+        for (i, j) in order:
+            ex = x[0, i] - x[0, j]
+            ey = x[1, i] - x[1, j]
+            n2 = 2.0 * (ex * ex + ey * ey)
+            if not n2 > 0.0:
+                continue
+            r = ex * (u[0, j] - u[0, i]) + ey * (u[1, j] - u[1, i]) - beta[(i, j)]
+            d = r / n2
+            mu_new = max(0.0, mu[(i, j)] + d)
+            delta = mu_new - mu[(i, j)]
+            mu[(i, j)] = mu_new
+            cx = delta * ex
+            cy = delta * ey
+            u[0, i] = u[0, i] + cx
+            u[1, i] = u[1, i] + cy
+            u[0, j] = u[0, j] - cx
+            u[1, j] = u[1, j] - cy
+            maxchg = max(maxchg, abs(cx), abs(cy))
+        sweeps += 1
+        umax = max(magnitude_limit, float(np.abs(u).max()))
+        if maxchg <= rtol * umax or sweeps >= max_sweeps:
+            break
+    return u, sweeps
+
+
+def _make_certificate(barrier_gain, unsafe_barrier_gain, safety_radius, magnitude_limit):
+    def f(dxi, x):
+        N = dxi.shape[1]
+        beta = {}
+        for i in range(N - 1):
+            for j in range(i + 1, N):
+                error = x[:, i] - x[:, j]
+                h = (error[0] * error[0] + error[1] * error[1]) - np.power(safety_radius, 2)
+                if h >= 0 or unsafe_barrier_gain is None:
+                    b = barrier_gain * np.power(h, 3)
+                else:
+                    b = unsafe_barrier_gain * np.power(h, 3)
+                beta[(i, j)] = 0.5 * b
+        # Threshold control inputs before QP (in place, as upstream)
+        norms = np.linalg.norm(dxi, 2, 0)
+        idxs_to_normalize = (norms > magnitude_limit)
+        dxi[:, idxs_to_normalize] *= magnitude_limit / norms[idxs_to_normalize]
+        u, _ = solve_pair_qp(dxi, x, beta, magnitude_limit=magnitude_limit)
+        return u
+    return f
+
+
+def create_single_integrator_barrier_certificate(barrier_gain=100, safety_radius=0.17, magnitude_limit=0.2):
+    return _make_certificate(barrier_gain, None, safety_radius, magnitude_limit)
+
+
+def create_single_integrator_barrier_certificate2(barrier_gain=100, unsafe_barrier_gain=1e6,
+                                                  safety_radius=0.17, magnitude_limit=0.2):
+    return _make_certificate(barrier_gain, unsafe_barrier_gain, safety_radius, magnitude_limit)

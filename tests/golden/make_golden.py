@@ -1,0 +1,224 @@
+"""Generate tests/golden/*.npz from the reference's own scenario code (run HERE only).
+
+    python tests/golden/make_golden.py
+
+Every fixture is a sequence of single env steps recorded teacher-forced: the full state
+before the step, the actions, everything `step()` returned, and the state after.  The
+simulator below the reference's layers is the restated rps (oracle/rps_restated), so these
+vectors pin rows a1, a2, a11-a16 of SURVEY.md section 8 bit-for-bit in float64 GIVEN that
+simulator; rows a4-a10 stay "parity unpinned" against real rps + cvxopt.
+
+Environment recorded with the vectors: numpy version (the neighbour order produced by
+np.argpartition is implementation-defined).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- policies
+def _toward(dx, dy):
+    if abs(dx) >= abs(dy):
+        return 1 if dx > 0 else 0
+    return 3 if dy > 0 else 2
+
+
+def policy_pcp(w, rng, eps):
+    s = w.env
+    acts = []
+    for a, ag in enumerate(s.agents):
+        if rng.rand() < eps:
+            acts.append(int(rng.randint(5)))
+            continue
+        p = s.agent_poses[:2, a]
+        best, bd = None, 1e9
+        for i in range(len(s.prey_loc)):
+            if s.prey_captured[i]:
+                continue
+            d = np.linalg.norm(p - s.prey_loc[i])
+            if d < bd:
+                best, bd = i, d
+        if best is None:
+            acts.append(4)
+        elif ag.capture_radius > 0 and bd <= ag.capture_radius * 0.9:
+            acts.append(4)
+        else:
+            dx, dy = s.prey_loc[best] - p
+            acts.append(_toward(dx, dy))
+    return acts
+
+
+def policy_warehouse(w, rng, eps):
+    s = w.env
+    acts = []
+    for a, ag in enumerate(s.agents):
+        if rng.rand() < eps:
+            acts.append(int(rng.randint(5)))
+            continue
+        p = s.agent_poses[:2, a]
+        if ag.loaded:
+            ty = 0.4 if ag.goal == 'Green' else -0.4
+            tx = -1.4
+        else:
+            ty = 0.4 if ag.goal == 'Red' else -0.4
+            tx = 1.4
+        if abs(p[1] - ty) > 0.25 and rng.rand() < 0.5:
+            acts.append(3 if ty > p[1] else 2)
+        else:
+            acts.append(1 if tx > p[0] else 0)
+    return acts
+
+
+def policy_mt(w, rng, eps):
+    s = w.env
+    acts = []
+    for a, ag in enumerate(s.agents):
+        msg = int(rng.randint(4))
+        if rng.rand() < eps:
+            acts.append(int(rng.randint(20)))
+            continue
+        p = s.agent_poses[:2, a]
+        if ag.load > 0:
+            mv = 0
+        elif a % 2 == 0 and s.zone1_load > 0:
+            dx, dy = -p[0], -p[1]
+            mv = 4 if np.hypot(dx, dy) < 0.2 else _toward(dx, dy)
+        elif s.zone2_load > 0:
+            mv = 1
+        elif s.zone1_load > 0:
+            dx, dy = -p[0], -p[1]
+            mv = 4 if np.hypot(dx, dy) < 0.2 else _toward(dx, dy)
+        else:
+            mv = 4
+        acts.append(mv * 4 + msg)
+    return acts
+
+
+POLICY = {"PredatorCapturePrey": policy_pcp, "Warehouse": policy_warehouse, "MaterialTransport": policy_mt}
+
+# ----------------------------------------------------------------------------- cases
+CASES = [
+    # name, scenario, overrides, seeds, steps per seed, eps (prob. of a uniformly random action)
+    ("pcp_n5", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, [11, 12, 13], 140, 0.35),
+    ("pcp_n4_default", "PredatorCapturePrey", {}, [21, 22], 120, 0.35),
+    ("pcp_n5_random", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, [31], 170, 1.0),
+    ("pcp_n6_capaware", "PredatorCapturePrey", {"predator": 3, "capture": 3, "n_agents": 6, "capability_aware": True,
+                                                "num_neighbors": 2}, [41], 100, 0.4),
+    ("warehouse_n8", "Warehouse", {"n_agents": 8}, [51, 52], 150, 0.3),
+    ("warehouse_n6_default", "Warehouse", {}, [61], 130, 0.3),
+    ("warehouse_n8_random", "Warehouse", {"n_agents": 8}, [71], 110, 1.0),
+    ("mt_n4_default", "MaterialTransport", {}, [81, 82], 100, 0.25),
+    ("mt_n6", "MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25},
+     [91, 92], 100, 0.25),
+    ("mt_n6_random", "MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25},
+     [95], 80, 1.0),
+    ("mt_n4_capaware", "MaterialTransport", {"capability_aware": True}, [97], 60, 0.3),
+]
+
+
+def run_case(name, scenario, overrides, seeds, steps, eps):
+    recs = []
+    first = []
+    cfg_out = None
+    for seed in seeds:
+        ov = dict(overrides)
+        ov["seed"] = seed
+        w, cfg = rh.make_reference_wrapper(scenario, ov)
+        cfg_out = cfg
+        rng = np.random.RandomState(1000 + seed)
+        rh.quiet_reset(w)
+        after_reset = True
+        for t in range(steps):
+            acts = POLICY[scenario](w, rng, eps)
+            rec = rh.step_record(w, scenario, acts)
+            recs.append(rec)
+            first.append(after_reset)
+            after_reset = False
+            if rec["done"]:
+                rh.quiet_reset(w)
+                after_reset = True
+    return recs, np.array(first, dtype=np.uint8), cfg_out
+
+
+def forced_violation_cases():
+    """Hand-placed poses that trip rps' validation (collision / boundary / both) on a later step;
+    one clean step is taken first (roboEnv.py:21 initialises its counters to ints, so a
+    violation on the very first validate of a process would raise in the reference)."""
+    out = []
+    for scenario, ov in (("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}),
+                         ("Warehouse", {"n_agents": 8}),
+                         ("MaterialTransport", {})):
+        for kind in ("collision", "boundary", "both", "barrier_unsafe", "late_boundary"):
+            ov2 = dict(ov)
+            ov2["seed"] = 5
+            if kind == "late_boundary":
+                ov2["RIGHT"] = 1.75   # goal beyond the arena: the robot drives out mid-step
+            w, cfg = rh.make_reference_wrapper(scenario, ov2)
+            rh.quiet_reset(w)
+            N = w.env.num_robots
+            noop = [4] * N if scenario != "MaterialTransport" else [16] * N
+            recs = [rh.step_record(w, scenario, noop)]
+            P = w.env.agent_poses  # live alias of the simulator state
+            acts = list(noop)
+            if kind in ("collision", "both"):
+                P[0, 1] = P[0, 0] + 0.09
+                P[1, 1] = P[1, 0] + 0.01
+                P[2, 1] = P[2, 0]
+            if kind in ("boundary", "both"):
+                P[0, N - 1] = 1.62
+                P[1, N - 1] = 0.3
+            if kind == "late_boundary":
+                P[0, N - 1], P[1, N - 1], P[2, N - 1] = 1.55, 0.3, 0.0
+                acts[N - 1] = 1 * 4 if scenario == "MaterialTransport" else 1
+            if kind == "barrier_unsafe":
+                # two robots inside each other's safety radius, commanded at each other: the
+                # certificate's unsafe branch (h < 0, gain 1e6) is active
+                P[0, 0], P[1, 0], P[2, 0] = 0.0, 0.0, 0.0
+                P[0, 1], P[1, 1], P[2, 1] = 0.19, 0.0, np.pi
+                if scenario == "MaterialTransport":
+                    acts[0], acts[1] = 1 * 4, 0 * 4
+                else:
+                    acts[0], acts[1] = 1, 0
+            recs.append(rh.step_record(w, scenario, acts))
+            out.append((f"viol_{scenario}_{kind}", scenario, cfg, recs))
+    return out
+
+
+def pack(recs):
+    keys = recs[0].keys()
+    return {k: np.stack([np.asarray(r[k]) for r in recs]) for k in keys}
+
+
+def main():
+    assert rh.reference_available(), "run in the build container (needs /root/reference)"
+    import json
+    for name, scenario, ov, seeds, steps, eps in CASES:
+        recs, first, cfg = run_case(name, scenario, ov, seeds, steps, eps)
+        d = pack(recs)
+        d["first_after_reset"] = first
+        d["seeds"] = np.array(seeds, dtype=np.int64)
+        d["steps_per_seed"] = np.int64(steps)
+        d["config_json"] = np.array(json.dumps(cfg))
+        d["scenario"] = np.array(scenario)
+        d["numpy_version"] = np.array(np.__version__)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        v = d["viol"]
+        print(f"{name}: T={len(recs)} done={int(d['done'].sum())} viol={int((v > 0).sum())} "
+              f"reward_sum={d['reward'][:, 0].sum():.3f}")
+    for name, scenario, cfg, recs in forced_violation_cases():
+        d = pack(recs)
+        d["first_after_reset"] = np.array([1] + [0] * (len(recs) - 1), dtype=np.uint8)
+        d["config_json"] = np.array(json.dumps(cfg))
+        d["scenario"] = np.array(scenario)
+        d["numpy_version"] = np.array(np.__version__)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(f"{name}: viol codes {d['viol'].tolist()} done {d['done'].tolist()}")
+
+
+if __name__ == "__main__":
+    main()

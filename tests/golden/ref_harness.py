@@ -1,0 +1,171 @@
+"""Drive the reference's OWN Python (Wrapper -> scenario -> roboEnv -> Controller) in this
+container, with the restated `rps` (oracle/rps_restated) injected for the absent third-party
+simulator and inert stand-ins for gym / tensorflow / imageio.
+
+Runs ONLY where /root/reference exists (the build container).  Nothing here is imported by
+the product, by `-m gpu` tests, smoke() or bench.py; the vectors it produces are committed
+as tests/golden/*.npz by make_golden.py.
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import yaml
+
+REFERENCE_ROOT = os.environ.get("MARBLER_REFERENCE", "/root/reference")
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "robotarium_gym"))
+
+
+def _install_stubs():
+    sys.dont_write_bytecode = True
+    if "gym" not in sys.modules:
+        gym = types.ModuleType("gym")
+        spaces = types.ModuleType("gym.spaces")
+
+        class _Space(object):
+            def __init__(self, *a, **k):
+                self.args = a
+                self.kwargs = k
+
+        class Discrete(_Space):
+            @property
+            def n(self):
+                return self.args[0]
+
+        class Box(_Space):
+            @property
+            def shape(self):
+                return self.kwargs.get("shape")
+
+        class Tuple(_Space):
+            @property
+            def spaces(self):
+                return self.args[0]
+
+            def __len__(self):
+                return len(self.args[0])
+
+            def __getitem__(self, i):
+                return self.args[0][i]
+
+        class Env(object):
+            def __init__(self):
+                pass
+
+        spaces.Discrete, spaces.Box, spaces.Tuple = Discrete, Box, Tuple
+        gym.spaces = spaces
+        gym.Env = Env
+        envs = types.ModuleType("gym.envs")
+        reg = types.ModuleType("gym.envs.registration")
+        reg.register = lambda *a, **k: None
+        envs.registration = reg
+        gym.envs = envs
+        sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.envs": envs,
+                            "gym.envs.registration": reg})
+    for name in ("tensorflow", "imageio"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    rps_dir = os.path.join(REPO_ROOT, "oracle", "rps_restated")
+    if rps_dir not in sys.path:
+        sys.path.insert(0, rps_dir)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+
+_SCENARIO_DIR = {"PredatorCapturePrey": "PredatorCapturePrey", "Warehouse": "Warehouse",
+                 "MaterialTransport": "MaterialTransport"}
+
+
+def load_reference_config(scenario):
+    path = os.path.join(REFERENCE_ROOT, "robotarium_gym", "scenarios", _SCENARIO_DIR[scenario], "config.yaml")
+    with open(path) as f:
+        return yaml.safe_load(f)
+
+
+def make_reference_wrapper(scenario, overrides, collision_variant="offset"):
+    """Returns (wrapper, config_dict).  Stdout of the reference is swallowed (it prints on
+    termination)."""
+    _install_stubs()
+    import rps.robotarium as rr
+    rr.COLLISION_VARIANT = collision_variant
+    rr._ERRORS.clear()
+    cfg = load_reference_config(scenario)
+    cfg.update({"show_figure_frequency": -1, "enable_logging": False, "save_gif": False,
+                "real_time": False, "robotarium": False})
+    cfg.update(overrides)
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        yaml.safe_dump(cfg, f)
+        path = f.name
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            from robotarium_gym.wrapper import Wrapper
+            w = Wrapper(scenario, path)
+    finally:
+        os.unlink(path)
+    return w, cfg
+
+
+_MSG = {"": 0, "collision": 1, "boundary": 2, "collision_boundary": 3}
+
+
+def quiet_reset(w):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return w.reset()
+
+
+def quiet_step(w, actions):
+    if hasattr(w.env, "prey_locs"):
+        # NumPy-2 incompatibility at PredatorCapturePrey.py:185 (`ndarray == []`); prey_locs is
+        # dead state, so it is cleared from outside and the reference stays untouched.
+        w.env.prey_locs = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        return w.step(actions)
+
+
+def snapshot_state(w, scenario):
+    """Full env state as the build represents it (see DESIGN.md 'state')."""
+    s = w.env
+    ro = s.env  # roboEnv
+    poses = np.array(s.agent_poses, dtype=np.float64)
+    if ro.previous_pose is None:
+        carry = np.zeros(poses.shape[1])
+    else:
+        carry = np.linalg.norm(poses[:2, :] - ro.previous_pose[:2, :], axis=0)
+    st = {"poses": poses.copy(), "carry": carry, "steps": np.int64(s.episode_steps)}
+    if scenario == "PredatorCapturePrey":
+        st["prey_loc"] = np.array(s.prey_loc, dtype=np.float64).copy()
+        st["prey_sensed"] = np.array(s.prey_sensed, dtype=np.uint8)
+        st["prey_captured"] = np.array(s.prey_captured, dtype=np.uint8)
+    elif scenario == "Warehouse":
+        st["loaded"] = np.array([a.loaded for a in s.agents], dtype=np.uint8)
+    elif scenario == "MaterialTransport":
+        st["load"] = np.array([a.load for a in s.agents], dtype=np.int64)
+        st["zone_load"] = np.array([s.zone1_load, s.zone2_load], dtype=np.int64)
+        st["messages"] = np.array(s.messages, dtype=np.int64)
+    return st
+
+
+def step_record(w, scenario, actions):
+    """One reference step; returns dict of pre-state, inputs, outputs, post-state."""
+    pre = snapshot_state(w, scenario)
+    obs, rew, done, info = quiet_step(w, list(int(a) for a in actions))
+    post = snapshot_state(w, scenario)
+    rec = {"pre_" + k: v for k, v in pre.items()}
+    rec.update({"post_" + k: v for k, v in post.items()})
+    rec["actions"] = np.array(actions, dtype=np.int64)
+    rec["obs"] = np.array([np.asarray(o, dtype=np.float64) for o in obs])
+    rec["reward"] = np.array(rew, dtype=np.float64)
+    rec["done"] = np.uint8(bool(done[0]))
+    assert all(bool(d) == bool(done[0]) for d in done)
+    rec["dist"] = np.array(info["dist_travelled"], dtype=np.float64)
+    rec["viol"] = np.uint8(_MSG[info.get("message", "")])
+    rec["remaining"] = np.int64(info["remaining"]) if "remaining" in info else np.int64(-1)
+    return rec
