@@ -1,0 +1,154 @@
+/* robogym.h -- C ABI of librobogym_hip.so: the MI355X-native (gfx950) vectorised
+ * Robotarium-gym step engine.
+ *
+ * Drop-in boundary.  Each entry point names the reference interface
+ * it replaces; paths are relative to /root/reference/robotarium_gym/.  The reference is pure
+ * Python and has no FFI of its own: the binding a maintainer would add is the ctypes layer in
+ * marbler_amd/_lib.py (shown in INTEGRATION.md).
+ *
+ * Conventions
+ *  - Every pointer in rg_state / rg_step_io / rg_step arguments is a DEVICE pointer into memory
+ *    owned by the caller (torch-ROCm tensors: `tensor.data_ptr()`).  The library never allocates
+ *    or frees caller-visible memory.
+ *  - All calls are asynchronous on the HIP stream given to rg_create; no call synchronises.
+ *  - Return value: 0 = OK, negative = error (text via rg_last_error()).  No exceptions cross
+ *    the ABI.  A handle is re-entrant across handles, not thread-safe within one.
+ *  - E envs, N agents per env, P prey, D per-agent observation length.
+ */
+#ifndef ROBOGYM_H
+#define ROBOGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_ABI_VERSION 1
+#define RG_MAX_AGENTS 16
+#define RG_MAX_PREY 64
+
+/* scenarios/<S>/ : wrapper.py:12-16 env_dict */
+enum { RG_SCN_PREDATOR_CAPTURE_PREY = 0, RG_SCN_WAREHOUSE = 1, RG_SCN_MATERIAL_TRANSPORT = 2 };
+/* rps _validate collision test */
+enum { RG_COLLISION_CENTER = 0, RG_COLLISION_OFFSET = 1 };
+/* info['message'] of the reference (utilities/roboEnv.py:82-94) as a code */
+enum { RG_VIOL_NONE = 0, RG_VIOL_COLLISION = 1, RG_VIOL_BOUNDARY = 2, RG_VIOL_COLLISION_BOUNDARY = 3 };
+
+/* Reset geometry of rps generate_initial_conditions (Appendix A.7) + the scenario's shift
+ * (misc.py:49-63, warehouse.py:93-98): N distinct cells of an nx x ny grid;
+ *   x = ((cx*spacing - w2) + ox1) + ox2,  y = ((cy*spacing - h2) + oy1) + oy2.
+ * nx, ny are computed by the host in float64 exactly as the reference does
+ * (floor(width/spacing), where width itself is a float64 difference of YAML values). */
+typedef struct rg_grid {
+    int32_t nx, ny;
+    float spacing, w2, h2, ox1, ox2, oy1, oy2;
+} rg_grid;
+
+/* The scenario config.yaml (scenarios/<S>/config.yaml, read by wrapper.py:27-31) plus the rps
+ * constants (Appendix A), flattened.  This is the block broadcast to every GPU at init. */
+typedef struct rg_scenario_params {
+    int32_t scenario;
+    int32_t n_agents;
+    int32_t obs_dim;                 /* D */
+    int32_t update_frequency;        /* U, roboEnv.py:52 */
+    int32_t controller_period;       /* 15, roboEnv.py:63 */
+    int32_t max_episode_steps;
+    int32_t penalize_violations;     /* roboEnv.py:82 */
+    int32_t barrier_has_unsafe_gain; /* 1 = certificate2 ('safe'), 0 = certificate ('default'), controller.py:13-16 */
+    int32_t collision_variant;       /* RG_COLLISION_* */
+    int32_t capability_aware;
+    int32_t num_prey;                /* P */
+    int32_t num_neighbors;           /* K */
+    int32_t torque[RG_MAX_AGENTS];   /* MaterialTransport.py:72-76 */
+    /* rps constants */
+    float time_step, bound_x0, bound_y0, bound_w, bound_h;
+    float robot_diameter, wheel_radius, max_linear_velocity;
+    float collision_offset, collision_diameter;
+    float projection_distance, angular_velocity_limit, position_velocity_limit;
+    float barrier_gain, unsafe_barrier_gain, safety_radius, barrier_magnitude_limit;
+    /* scenario */
+    float left, right, up, down;
+    float agent_step[RG_MAX_AGENTS];     /* step_dist, or MaterialTransport per-agent speed */
+    float sensing_radius[RG_MAX_AGENTS]; /* PredatorCapturePrey.py:40-44 */
+    float capture_radius[RG_MAX_AGENTS];
+    float time_penalty, sense_reward, capture_reward, violation_reward;
+    float load_reward, unload_reward, goal_width;
+    float unload_multiplier, load_multiplier, end_goal_width, zone1_radius;
+    /* reset (misc.py:49-63, scenario reset()) */
+    rg_grid agent_grid, prey_grid;
+    int32_t keep_theta;              /* Warehouse keeps the sampled heading, misc.py:58,62 zero it */
+    float zone1_mean, zone1_std, zone2_mean, zone2_std; /* MaterialTransport.py:99-100 */
+} rg_scenario_params;
+
+/* Env state in HBM (replaces the Python objects: scenario.agent_poses 3xN = the live alias of
+ * rps.Robotarium.poses, roboEnv.previous_pose, scenario.episode_steps, prey / loaded / load /
+ * zone / message attributes).  Arrays a scenario does not use may be NULL. */
+typedef struct rg_state {
+    float *poses;           /* [E][3][N]: x row, y row, theta row, as the reference's 3xN */
+    float *carry_dist;      /* [E][N]: length of the last sub-iteration of the previous step, not yet
+                               added to dist_travelled (roboEnv.py:55-59 lags one iteration) */
+    int32_t *episode_steps; /* [E] */
+    int32_t *reset_count;   /* [E] episodes started so far (RNG stream position) */
+    float *prey_loc;        /* [E][P][2]   PredatorCapturePrey */
+    uint8_t *prey_sensed;   /* [E][P] */
+    uint8_t *prey_captured; /* [E][P] */
+    uint8_t *loaded;        /* [E][N]      Warehouse */
+    int32_t *load;          /* [E][N]      MaterialTransport */
+    int32_t *zone_load;     /* [E][2] */
+    int32_t *messages;      /* [E][4] */
+} rg_state;
+
+/* Everything Wrapper.step returns (wrapper.py:41-44), batched. */
+typedef struct rg_step_io {
+    float *obs;            /* [E][N][D] */
+    float *reward;         /* [E][N] */
+    uint8_t *done;         /* [E]  (the reference repeats it N times) */
+    float *dist_travelled; /* [E][N]  info['dist_travelled'] */
+    uint8_t *violation;    /* [E]     info['message'] as RG_VIOL_* */
+    int32_t *remaining;    /* [E]     info['remaining'], -1 when the reference omits the key */
+    int32_t *qp_sweeps;    /* [E] or NULL: diagnostic, max barrier-QP sweeps in this step */
+} rg_step_io;
+
+typedef struct rg_handle rg_handle;
+
+int rg_abi_version(void);
+const char *rg_last_error(void);
+/* sizeof(rg_scenario_params / rg_state / rg_step_io) as compiled, for binding self-checks */
+int rg_sizeof_params(void);
+int rg_sizeof_state(void);
+int rg_sizeof_step_io(void);
+
+/* Replaces Wrapper.__init__ -> scenario.__init__ -> roboEnv.__init__ -> Controller.__init__
+ * (wrapper.py:20-34, PredatorCapturePrey.py:15-59, roboEnv.py:12-24, controller.py:5-18).
+ * `env_offset` is the global index of this shard's env 0 (RNG streams are keyed by global env
+ * index, so results do not depend on how envs are sharded over GPUs). */
+rg_handle *rg_create(const rg_scenario_params *params, int32_t num_envs, int64_t env_offset, int32_t device,
+                     void *hip_stream);
+int rg_destroy(rg_handle *h);
+
+/* Binds the caller-owned state arrays.  Must be called before reset/step. */
+int rg_bind_state(rg_handle *h, const rg_state *state);
+
+/* Replaces scenario.reset() + roboEnv.reset() (PredatorCapturePrey.py:114-136, warehouse.py:84-100,
+ * MaterialTransport.py:94-111, roboEnv.py:27-36,98-118, misc.py:49-63).  mask: [E] uint8 device
+ * pointer, nonzero = reset that env; NULL = all. */
+int rg_reset(rg_handle *h, const uint8_t *mask, uint64_t seed);
+
+/* Replaces Wrapper.step -> scenario.step -> roboEnv.step -> Controller.set_velocities ->
+ * rps.Robotarium.{get_poses,set_velocities,step} and the scenario's tracking / observation /
+ * reward / termination code (wrapper.py:41-44, PredatorCapturePrey.py:138-216, warehouse.py:102-178,
+ * MaterialTransport.py:113-189, roboEnv.py:38-96, controller.py:20-24).
+ * actions: [E][N] int32.  If auto_reset != 0, envs that finish are reset in the same launch
+ * (their returned obs/reward/done are those of the terminal step). */
+int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t auto_reset, uint64_t seed);
+
+/* The observation the scenario would build from the current state without stepping (the
+ * reference returns zeros from reset(), PredatorCapturePrey.py:136; EPyMARL's gymma layer is
+ * where get_obs() lives).  obs: [E][N][D]. */
+int rg_get_obs(rg_handle *h, float *obs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBOGYM_H */

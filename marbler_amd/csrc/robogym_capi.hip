@@ -1,0 +1,175 @@
+// robogym_capi.hip -- the C ABI declared in include/robogym.h (host side).
+//
+// Plain pointers and sizes in, status codes out; no torch types.  The handle owns nothing on
+// the device: state and outputs live in caller-owned HBM (torch-ROCm tensors).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/robogym.h"
+#include "kernel_args.h"
+
+struct rg_handle {
+    rg_scenario_params params;
+    rg_state state;
+    int32_t num_envs;
+    int64_t env_offset;
+    int32_t device;
+    hipStream_t stream;
+    bool bound;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+static int check_params(const rg_scenario_params *p) {
+    if (!p) return fail(-1, "params is NULL");
+    if (p->scenario < RG_SCN_PREDATOR_CAPTURE_PREY || p->scenario > RG_SCN_MATERIAL_TRANSPORT)
+        return fail(-2, "unknown scenario id");
+    if (p->n_agents < 1 || p->n_agents > RG_MAX_AGENTS) return fail(-3, "n_agents must be in 1..16");
+    if (p->update_frequency < 1 || p->controller_period < 1) return fail(-4, "update_frequency / controller_period < 1");
+    if (p->obs_dim < 1) return fail(-5, "obs_dim < 1");
+    if (p->collision_variant != RG_COLLISION_CENTER && p->collision_variant != RG_COLLISION_OFFSET)
+        return fail(-6, "unknown collision_variant");
+    const rg_grid &g = p->agent_grid;
+    // rps generate_initial_conditions asserts cells > N (Appendix A.7)
+    if (g.nx < 1 || g.ny < 1 || g.nx * g.ny <= p->n_agents || g.nx * g.ny > 64)
+        return fail(-7, "agent reset grid must have n_agents < nx*ny <= 64");
+    if (p->scenario == RG_SCN_PREDATOR_CAPTURE_PREY) {
+        if (p->num_prey < 1 || p->num_prey > RG_MAX_PREY) return fail(-8, "num_prey must be in 1..64");
+        const rg_grid &q = p->prey_grid;
+        if (q.nx < 1 || q.ny < 1 || q.nx * q.ny <= p->num_prey || q.nx * q.ny > 64)
+            return fail(-9, "prey reset grid must have num_prey < nx*ny <= 64");
+        const int od = p->capability_aware ? 6 : 4;
+        const int nb = p->num_neighbors >= p->n_agents - 1 ? p->n_agents - 1 : p->num_neighbors;
+        if (p->obs_dim < od * (nb + 1)) return fail(-10, "obs_dim too small for PredatorCapturePrey");
+    } else if (p->scenario == RG_SCN_WAREHOUSE) {
+        const int nb = p->num_neighbors >= p->n_agents - 1 ? p->n_agents - 1 : p->num_neighbors;
+        if (p->obs_dim < 3 * (nb + 1)) return fail(-10, "obs_dim too small for Warehouse");
+    } else {
+        if (p->obs_dim < (p->capability_aware ? 11 : 9)) return fail(-10, "obs_dim too small for MaterialTransport");
+    }
+    return 0;
+}
+
+extern "C" {
+
+int rg_abi_version(void) { return RG_ABI_VERSION; }
+
+const char *rg_last_error(void) { return g_err; }
+
+int rg_sizeof_params(void) { return static_cast<int>(sizeof(rg_scenario_params)); }
+int rg_sizeof_state(void) { return static_cast<int>(sizeof(rg_state)); }
+int rg_sizeof_step_io(void) { return static_cast<int>(sizeof(rg_step_io)); }
+
+rg_handle *rg_create(const rg_scenario_params *params, int32_t num_envs, int64_t env_offset, int32_t device,
+                     void *hip_stream) {
+    if (check_params(params) != 0) return nullptr;
+    if (num_envs < 1) {
+        fail(-11, "num_envs < 1");
+        return nullptr;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) {
+        fail(-12, "no HIP device visible: librobogym_hip has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        fail(-13, "device index out of range");
+        return nullptr;
+    }
+    rg_handle *h = new (std::nothrow) rg_handle();
+    if (!h) {
+        fail(-14, "out of host memory");
+        return nullptr;
+    }
+    h->params = *params;
+    memset(&h->state, 0, sizeof(h->state));
+    h->num_envs = num_envs;
+    h->env_offset = env_offset;
+    h->device = device;
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    h->bound = false;
+    return h;
+}
+
+int rg_destroy(rg_handle *h) {
+    if (!h) return fail(-1, "handle is NULL");
+    delete h;
+    return 0;
+}
+
+int rg_bind_state(rg_handle *h, const rg_state *st) {
+    if (!h || !st) return fail(-1, "handle or state is NULL");
+    if (!st->poses || !st->carry_dist || !st->episode_steps || !st->reset_count)
+        return fail(-20, "poses, carry_dist, episode_steps and reset_count are required");
+    switch (h->params.scenario) {
+        case RG_SCN_PREDATOR_CAPTURE_PREY:
+            if (!st->prey_loc || !st->prey_sensed || !st->prey_captured)
+                return fail(-21, "PredatorCapturePrey needs prey_loc, prey_sensed, prey_captured");
+            break;
+        case RG_SCN_WAREHOUSE:
+            if (!st->loaded) return fail(-21, "Warehouse needs loaded");
+            break;
+        default:
+            if (!st->load || !st->zone_load || !st->messages)
+                return fail(-21, "MaterialTransport needs load, zone_load, messages");
+    }
+    h->state = *st;
+    h->bound = true;
+    return 0;
+}
+
+static int fill_args(rg_handle *h, rg::KernelArgs &a) {
+    if (!h) return fail(-1, "handle is NULL");
+    if (!h->bound) return fail(-22, "rg_bind_state has not been called");
+    memset(&a, 0, sizeof(a));
+    a.p = h->params;
+    a.st = h->state;
+    a.E = h->num_envs;
+    a.env_offset = h->env_offset;
+    return 0;
+}
+
+static int launched(hipError_t err) {
+    if (err != hipSuccess) return fail(-30, "kernel launch failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int rg_reset(rg_handle *h, const uint8_t *mask, uint64_t seed) {
+    rg::KernelArgs a;
+    if (int rc = fill_args(h, a)) return rc;
+    a.reset_mask = mask;
+    a.seed = seed;
+    return launched(rg::launch_reset(a, h->stream));
+}
+
+int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t auto_reset, uint64_t seed) {
+    rg::KernelArgs a;
+    if (int rc = fill_args(h, a)) return rc;
+    if (!actions || !io) return fail(-23, "actions or io is NULL");
+    if (!io->obs || !io->reward || !io->done || !io->dist_travelled || !io->violation || !io->remaining)
+        return fail(-24, "every rg_step_io array except qp_sweeps is required");
+    a.actions = actions;
+    a.io = *io;
+    a.auto_reset = auto_reset;
+    a.seed = seed;
+    return launched(rg::launch_step(a, false, h->stream));
+}
+
+int rg_get_obs(rg_handle *h, float *obs) {
+    rg::KernelArgs a;
+    if (int rc = fill_args(h, a)) return rc;
+    if (!obs) return fail(-23, "obs is NULL");
+    a.io.obs = obs;
+    return launched(rg::launch_step(a, true, h->stream));
+}
+
+}  // extern "C"

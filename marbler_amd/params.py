@@ -1,0 +1,177 @@
+"""Scenario config (the reference's YAML keys, verbatim) -> rg_scenario_params.
+
+Mirrors what the reference does with `objectview(yaml)` in wrapper.py:27-31 and the scenario
+constructors (PredatorCapturePrey.py:15-59, warehouse.py:48-82, MaterialTransport.py:49-92),
+plus the rps constants of SURVEY.md Appendix A and the reset geometry of misc.py:49-63.
+All derived integers (grid sizes) are computed in float64 exactly as the reference does.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import yaml
+
+from ._lib import MAX_AGENTS, MAX_PREY, RgGrid, RgScenarioParams
+
+SCENARIO_IDS = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2}
+COLLISION_VARIANTS = {"center": 0, "offset": 1}
+CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+
+# sim_spec_v0: which of the two upstream collision tests rps' _validate uses (SURVEY.md
+# Appendix A.4).  'offset' = centres shifted 0.025 m along the heading, distance <= 0.135 m:
+# the variant that ships with the per-robot dict counters the reference reads
+# (roboEnv.py:84-86).  Override with config key `collision_variant: center`.
+DEFAULT_COLLISION_VARIANT = "offset"
+
+
+def default_config_path(scenario):
+    return os.path.join(CONFIG_DIR, scenario + ".yaml")
+
+
+def load_config(scenario, config_path=None, overrides=None):
+    with open(config_path or default_config_path(scenario), "r") as f:
+        cfg = yaml.safe_load(f)
+    if overrides:
+        cfg.update(overrides)
+    return cfg
+
+
+def _grid(count, width, height, spacing, what):
+    """rps generate_initial_conditions (Appendix A.7) geometry."""
+    nx = int(np.floor(width / spacing))
+    ny = int(np.floor(height / spacing))
+    if nx == 0 or ny == 0:
+        raise ValueError(f"{what}: spacing {spacing} too large for a {width} x {height} area")
+    if not nx * ny > count:
+        raise ValueError(f"{what}: {count} items need more than {nx}x{ny} = {nx * ny} grid cells "
+                         f"(rps asserts cells > N; lower the spacing)")
+    if nx * ny > 64:
+        raise ValueError(f"{what}: {nx}x{ny} grid exceeds the 64 cells the device sampler supports")
+    g = RgGrid()
+    g.nx, g.ny, g.spacing, g.w2, g.h2 = nx, ny, spacing, width / 2, height / 2
+    return g
+
+
+def _dummy_grid():
+    g = RgGrid()
+    g.nx = g.ny = 1
+    return g
+
+
+def _check_agents(N):
+    if not 1 <= N <= MAX_AGENTS:
+        raise ValueError(f"n_agents must be in 1..{MAX_AGENTS}")
+
+
+def make_params(scenario, cfg):
+    if scenario not in SCENARIO_IDS:
+        raise KeyError(f"scenario {scenario!r} is not built (have {sorted(SCENARIO_IDS)})")
+    p = RgScenarioParams()
+    p.scenario = SCENARIO_IDS[scenario]
+    p.update_frequency = int(cfg["update_frequency"])
+    p.controller_period = 15                                   # roboEnv.py:63
+    p.max_episode_steps = int(cfg["max_episode_steps"])
+    p.penalize_violations = int(bool(cfg["penalize_violations"]))
+    if cfg.get("robotarium", False) or cfg.get("real_time", False):
+        raise ValueError("robotarium / real_time runs drive the physical testbed and are out of scope")
+    bc = cfg.get("barrier_certificate", "safe")                # roboEnv.py:15-18
+    if bc not in ("safe", "default"):
+        raise ValueError("barrier_certificate must be 'safe' or 'default' (custom closures are not supported)")
+    p.barrier_has_unsafe_gain = 1 if bc == "safe" else 0       # controller.py:13-16
+    p.safety_radius = 0.2 if bc == "safe" else 0.17
+    p.barrier_gain, p.unsafe_barrier_gain, p.barrier_magnitude_limit = 100.0, 1e6, 0.2
+    p.collision_variant = COLLISION_VARIANTS[cfg.get("collision_variant", DEFAULT_COLLISION_VARIANT)]
+    p.time_step = 0.033
+    p.bound_x0, p.bound_y0, p.bound_w, p.bound_h = -1.6, -1.0, 3.2, 2.0
+    p.robot_diameter, p.wheel_radius, p.max_linear_velocity = 0.11, 0.016, 0.2
+    p.collision_offset, p.collision_diameter = 0.025, 0.135
+    p.projection_distance, p.angular_velocity_limit, p.position_velocity_limit = 0.05, math.pi, 0.15
+    L, R, U, D = cfg["LEFT"], cfg["RIGHT"], cfg["UP"], cfg["DOWN"]
+    p.left, p.right, p.up, p.down = L, R, U, D
+    height = D - U
+    if scenario == "PredatorCapturePrey":
+        npred, ncap = int(cfg["predator"]), int(cfg["capture"])
+        N = npred + ncap
+        p.n_agents = N
+        _check_agents(N)
+        p.capability_aware = int(bool(cfg["capability_aware"]))
+        p.num_prey = int(cfg["num_prey"])
+        if not 1 <= p.num_prey <= MAX_PREY:
+            raise ValueError(f"num_prey must be in 1..{MAX_PREY}")
+        p.num_neighbors = int(cfg["num_neighbors"])
+        p.obs_dim = (6 if p.capability_aware else 4) * (p.num_neighbors + 1)
+        for a in range(N):
+            p.agent_step[a] = cfg["step_dist"]
+            p.sensing_radius[a] = cfg["predator_radius"] if a < npred else 0.0
+            p.capture_radius[a] = 0.0 if a < npred else cfg["capture_radius"]
+        p.time_penalty, p.sense_reward, p.capture_reward = \
+            cfg["time_penalty"], cfg["sense_reward"], cfg["capture_reward"]
+        p.violation_reward = -5.0                               # PredatorCapturePrey.py:159
+        thresh = cfg["ROBOT_INIT_RIGHT_THRESH"]
+        width = thresh - L                                     # PredatorCapturePrey.py:123-125
+        g = _grid(N, width, height, cfg["start_dist"], "agents")
+        g.ox1 = -(width / 2 - thresh)                           # misc.py:57
+        p.agent_grid = g
+        width = R - cfg["PREY_INIT_LEFT_THRESH"]               # :128-129 (shift uses ROBOT_INIT_RIGHT_THRESH)
+        q = _grid(p.num_prey, width, height, cfg["step_dist"], "prey")
+        q.ox1 = (width / 2 - thresh)                            # misc.py:61
+        p.prey_grid = q
+        p.keep_theta = 0
+    elif scenario == "Warehouse":
+        N = int(cfg["n_agents"])
+        p.n_agents = N
+        _check_agents(N)
+        p.num_neighbors = int(cfg["num_neighbors"])
+        p.obs_dim = 3 * (p.num_neighbors + 1)
+        for a in range(N):
+            p.agent_step[a] = cfg["step_dist"]
+        p.load_reward, p.unload_reward, p.goal_width = cfg["load_reward"], cfg["unload_reward"], cfg["goal_width"]
+        p.violation_reward = -5.0                               # warehouse.py:116
+        g = _grid(N, R - L, height, cfg["start_dist"], "agents")   # warehouse.py:90-98
+        g.ox1, g.ox2 = (1.5 + L) / 2, -((1.5 - R) / 2)
+        g.oy1, g.oy2 = -((1 + U) / 2), (1 - D) / 2
+        p.agent_grid = g
+        p.prey_grid = _dummy_grid()
+        p.keep_theta = 1
+    else:
+        nf, ns = int(cfg["n_fast_agents"]), int(cfg["n_slow_agents"])
+        N = int(cfg["n_agents"])
+        if nf + ns != N:
+            raise ValueError("n_fast_agents + n_slow_agents must equal n_agents")
+        if N < 4:
+            raise ValueError("MaterialTransport broadcasts the messages of agents 0-3: n_agents >= 4")
+        p.n_agents = N
+        _check_agents(N)
+        p.capability_aware = int(bool(cfg["capability_aware"]))
+        p.obs_dim = 11 if p.capability_aware else 9
+        for a in range(N):
+            p.agent_step[a] = cfg["fast_step"] if a < nf else cfg["slow_step"]
+            p.torque[a] = int(cfg["small_torque"] if a < nf else cfg["large_torque"])
+        p.time_penalty = cfg["time_penalty"]
+        p.unload_multiplier, p.load_multiplier = cfg["unload_multiplier"], cfg["load_multiplier"]
+        p.end_goal_width, p.zone1_radius = cfg["end_goal_width"], cfg["zone1_radius"]
+        p.violation_reward = -6.0                               # MaterialTransport.py:137
+        for z in ("zone1", "zone2"):
+            if cfg[z].get("distribution", "normal") != "normal":
+                raise ValueError("only the 'normal' zone distribution of the reference config is built")
+        p.zone1_mean, p.zone1_std = cfg["zone1"]["loc"], cfg["zone1"]["scale"]
+        p.zone2_mean, p.zone2_std = cfg["zone2"]["loc"], cfg["zone2"]["scale"]
+        width = cfg["end_goal_width"]                           # MaterialTransport.py:106-109
+        thresh = L + cfg["end_goal_width"]
+        g = _grid(N, width, height, cfg["start_dist"], "agents")
+        g.ox1 = -(width / 2 - thresh)
+        p.agent_grid = g
+        p.prey_grid = _dummy_grid()
+        p.keep_theta = 0
+    return p
+
+
+def params_to_bytes(p):
+    return bytes(ctypes.string_at(ctypes.addressof(p), ctypes.sizeof(p)))
+
+
+def params_from_bytes(b):
+    p = RgScenarioParams()
+    ctypes.memmove(ctypes.addressof(p), bytes(b), ctypes.sizeof(p))
+    return p

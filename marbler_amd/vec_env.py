@@ -1,0 +1,165 @@
+"""VecRobotariumEnv -- E independent Robotarium-gym envs stepped by one HIP launch.
+
+Host-side mirror of the reference's env surface (wrapper.py:19-50 over scenarios/<S>):
+`reset()`, `step(actions)`, plus `get_obs()` (the name EPyMARL's gymma layer uses), all on
+torch-ROCm tensors.  State lives in HBM as torch tensors this object owns; the kernels
+(librobogym_hip.so, include/robogym.h) read and write them in place.
+
+Shapes (E envs, N agents, D per-agent obs length):
+    obs [E,N,D] f32 | reward [E,N] f32 | done [E] bool
+    info: dist_travelled [E,N] f32, violation [E] u8 (0 '', 1 collision, 2 boundary,
+          3 collision_boundary = info['message']), remaining [E] i32 (-1 = key absent)
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .params import load_config, make_params
+
+VIOLATION_MESSAGES = ("", "collision", "boundary", "collision_boundary")  # roboEnv.py:82-94
+
+
+class VecRobotariumEnv(object):
+    def __init__(self, scenario, num_envs, config_path=None, overrides=None, device="cuda:0", seed=0,
+                 env_offset=0, auto_reset=True, reference_reset_obs=True, params=None, collect_qp_stats=False):
+        """scenario: 'PredatorCapturePrey' | 'Warehouse' | 'MaterialTransport' (wrapper.py:12-16).
+        config_path / overrides: the reference's scenario YAML (same keys) and a dict of overrides.
+        env_offset: global index of env 0 of this shard (RNG streams are keyed by global index).
+        auto_reset: finished envs are reset inside the step launch.
+        reference_reset_obs: reset() returns zeros like the reference (PredatorCapturePrey.py:136);
+            False returns the observation of the fresh state (get_obs()).
+        params: a ready RgScenarioParams (e.g. received by broadcast) instead of a config."""
+        self.lib = _lib.load()
+        self.scenario = scenario
+        self.cfg = None
+        if params is None:
+            self.cfg = load_config(scenario, config_path, overrides)
+            params = make_params(scenario, self.cfg)
+        self.params = params
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.RobogymError("VecRobotariumEnv runs on an AMD GPU only (device='cuda:N'); no CPU path exists")
+        if not torch.cuda.is_available():
+            raise _lib.RobogymError("no HIP device visible to torch; marbler_amd has no CPU fallback")
+        self.E = int(num_envs)
+        self.N = int(params.n_agents)
+        self.D = int(params.obs_dim)
+        self.P = int(params.num_prey)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.env_offset = int(env_offset)
+        self.auto_reset = bool(auto_reset)
+        self.reference_reset_obs = bool(reference_reset_obs)
+        E, N, D, P = self.E, self.N, self.D, max(self.P, 1)
+        dev = self.device
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        # ---- state (rg_state)
+        self.poses = torch.zeros(E, 3, N, dtype=f32, device=dev)
+        self.carry_dist = torch.zeros(E, N, dtype=f32, device=dev)
+        self.episode_steps = torch.zeros(E, dtype=i32, device=dev)
+        self.reset_count = torch.zeros(E, dtype=i32, device=dev)
+        self.prey_loc = torch.zeros(E, P, 2, dtype=f32, device=dev)
+        self.prey_sensed = torch.zeros(E, P, dtype=u8, device=dev)
+        self.prey_captured = torch.zeros(E, P, dtype=u8, device=dev)
+        self.loaded = torch.zeros(E, N, dtype=u8, device=dev)
+        self.load = torch.zeros(E, N, dtype=i32, device=dev)
+        self.zone_load = torch.zeros(E, 2, dtype=i32, device=dev)
+        self.messages = torch.zeros(E, 4, dtype=i32, device=dev)
+        # ---- step outputs (rg_step_io)
+        self.obs = torch.zeros(E, N, D, dtype=f32, device=dev)
+        self.reward = torch.zeros(E, N, dtype=f32, device=dev)
+        self.done_u8 = torch.zeros(E, dtype=u8, device=dev)
+        self.dist_travelled = torch.zeros(E, N, dtype=f32, device=dev)
+        self.violation = torch.zeros(E, dtype=u8, device=dev)
+        self.remaining = torch.full((E,), -1, dtype=i32, device=dev)
+        self.qp_sweeps = torch.zeros(E, dtype=i32, device=dev) if collect_qp_stats else None
+
+        self._stream = torch.cuda.current_stream(dev)
+        self._h = self.lib.rg_create(C.byref(params), self.E, self.env_offset, dev.index or 0,
+                                     C.c_void_p(self._stream.cuda_stream))
+        if not self._h:
+            raise _lib.RobogymError("rg_create failed: " + self.lib.rg_last_error().decode())
+        st = _lib.RgState(*(t.data_ptr() for t in (
+            self.poses, self.carry_dist, self.episode_steps, self.reset_count, self.prey_loc, self.prey_sensed,
+            self.prey_captured, self.loaded, self.load, self.zone_load, self.messages)))
+        _lib.check(self.lib.rg_bind_state(self._h, C.byref(st)), "rg_bind_state")
+        self._io = _lib.RgStepIO(self.obs.data_ptr(), self.reward.data_ptr(), self.done_u8.data_ptr(),
+                                 self.dist_travelled.data_ptr(), self.violation.data_ptr(),
+                                 self.remaining.data_ptr(),
+                                 self.qp_sweeps.data_ptr() if self.qp_sweeps is not None else None)
+        self._io_ref = C.byref(self._io)
+        self._actions_i32 = torch.zeros(E, N, dtype=i32, device=dev)
+
+    # ------------------------------------------------------------------ reference surface
+    @property
+    def n_agents(self):
+        return self.N
+
+    @property
+    def num_envs(self):
+        return self.E
+
+    def reset(self, mask=None):
+        """scenario.reset() for all envs (mask=None) or those with mask != 0.  Returns obs [E,N,D]:
+        zeros where the reference would (reference_reset_obs), else the fresh observation."""
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mptr = mask.data_ptr()
+        _lib.check(self.lib.rg_reset(self._h, mptr, self.seed), "rg_reset")
+        if self.reference_reset_obs:
+            if mask is None:
+                self.obs.zero_()
+            else:
+                self.obs[mask.bool()] = 0
+            return self.obs
+        return self.get_obs()
+
+    def step(self, actions):
+        """actions: int tensor [E,N] on the device (int32 is used as is; other int dtypes are
+        converted).  Returns (obs, reward, done, info) as views of the env's output buffers --
+        they are overwritten by the next step."""
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            self._actions_i32.copy_(actions.reshape(self.E, self.N))
+            actions = self._actions_i32
+        rc = self.lib.rg_step(self._h, actions.data_ptr(), self._io_ref, 1 if self.auto_reset else 0, self.seed)
+        if rc != 0:
+            _lib.check(rc, "rg_step")
+        return self.obs, self.reward, self.done_u8.bool(), self.info
+
+    @property
+    def info(self):
+        return {"dist_travelled": self.dist_travelled, "violation": self.violation, "remaining": self.remaining}
+
+    def step_raw(self, actions_ptr):
+        """Hot-loop entry: one rg_step on a pre-validated device pointer to int32 [E,N]; results are
+        in self.obs / reward / done_u8 / dist_travelled / violation / remaining."""
+        return self.lib.rg_step(self._h, actions_ptr, self._io_ref, 1 if self.auto_reset else 0, self.seed)
+
+    def get_obs(self, out=None):
+        """Observation of the current state without stepping (gymma's get_obs())."""
+        out = self.obs if out is None else out
+        _lib.check(self.lib.rg_get_obs(self._h, out.data_ptr()), "rg_get_obs")
+        return out
+
+    # ------------------------------------------------------------------ state access (parity / checkpoints)
+    STATE_KEYS = ("poses", "carry_dist", "episode_steps", "reset_count", "prey_loc", "prey_sensed", "prey_captured",
+                  "loaded", "load", "zone_load", "messages")
+
+    def state_dict(self):
+        return {k: getattr(self, k).clone() for k in self.STATE_KEYS}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            getattr(self, k).copy_(torch.as_tensor(v).to(getattr(self, k).dtype).reshape(getattr(self, k).shape))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.rg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,119 @@
+"""Single-env facade with the reference's exact Python-level surface (robotarium_gym/wrapper.py).
+
+`Wrapper(env_name, config_path)` is what the gym ids `robotarium_gym:<Scenario>-v0` construct
+(__init__.py:4-23).  It returns what the reference returns, type for type:
+    reset() -> list of N lists of zeros                       (PredatorCapturePrey.py:136)
+    step(action_n) -> (tuple of N float64 arrays [D], list of N rewards, list of N bools,
+                       info dict: 'dist_travelled' float64[N], 'message' str if a violation
+                       ended the episode, 'remaining' int when the scenario reports it)
+The arithmetic runs on the GPU through VecRobotariumEnv with E = 1; this class exists for
+drop-in compatibility (EPyMARL's gymma wrapper, evaluation scripts), not for throughput.
+"""
+import numpy as np
+import torch
+
+from .params import default_config_path
+from .spaces import scenario_spaces
+from .vec_env import VIOLATION_MESSAGES, VecRobotariumEnv
+
+SCENARIOS = ("PredatorCapturePrey", "Warehouse", "MaterialTransport")
+
+
+class _ScenarioFacade(object):
+    """What `Wrapper.env` exposes in the reference (scenarios/base.py): num_robots, agent_poses,
+    args, get_action_space / get_observation_space, reset, step."""
+
+    def __init__(self, env_name, config_path, device):
+        self.vec = VecRobotariumEnv(env_name, 1, config_path=config_path, device=device, auto_reset=False,
+                                    reference_reset_obs=True)
+        cfg = self.vec.cfg
+        if cfg.get("seed", -1) != -1:
+            self.vec.seed = int(cfg["seed"])
+        self.args = type("objectview", (), dict(cfg))()
+        self.num_robots = self.vec.N
+        self.action_space, self.observation_space = scenario_spaces(env_name, self.vec.params)
+        self._scenario = env_name
+
+    @property
+    def agent_poses(self):
+        return self.vec.poses[0].double().cpu().numpy()          # 3 x N, like the reference
+
+    def get_action_space(self):
+        return self.action_space
+
+    def get_observation_space(self):
+        return self.observation_space
+
+    def reset(self):
+        self.vec.reset()
+        return [[0] * self.vec.D] * self.num_robots
+
+    def step(self, actions_):
+        a = torch.as_tensor(np.asarray(actions_, dtype=np.int32).reshape(1, self.num_robots), device=self.vec.device)
+        obs, rew, done, info = self.vec.step(a)
+        obs = obs[0].double().cpu().numpy()
+        rew = rew[0].double().cpu().numpy()
+        terminated = bool(done[0].item())
+        out = {}
+        viol = int(info["violation"][0].item())
+        if viol:
+            out["message"] = VIOLATION_MESSAGES[viol]
+        rem = int(info["remaining"][0].item())
+        if rem >= 0:
+            out["remaining"] = rem
+        out["dist_travelled"] = info["dist_travelled"][0].double().cpu().numpy()
+        return [obs[i] for i in range(self.num_robots)], [float(r) for r in rew], \
+            [terminated] * self.num_robots, out
+
+    def render(self, mode='human'):
+        pass
+
+
+env_dict = {name: name for name in SCENARIOS}  # wrapper.py:12-16 (Simple / ArcticTransport: not built yet)
+
+
+class Wrapper(object):
+    def __init__(self, env_name, config_path=None, device="cuda:0"):
+        if env_name not in env_dict:
+            raise KeyError(f"scenario {env_name!r} is not built (have {sorted(env_dict)})")
+        self.env = _ScenarioFacade(env_name, config_path or default_config_path(env_name), device)
+        self.observation_space = self.get_observation_space()
+        self.action_space = self.get_action_space()
+        self.n_agents = self.env.num_robots
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, action_n):
+        obs_n, reward_n, done_n, info_n = self.env.step(action_n)
+        return tuple(obs_n), reward_n, done_n, info_n
+
+    def get_action_space(self):
+        return self.env.get_action_space()
+
+    def get_observation_space(self):
+        return self.env.get_observation_space()
+
+    def render(self, mode='human'):
+        pass
+
+    def close(self):
+        self.env.vec.close()
+
+
+def register_gym_ids(entry_point="marbler_amd.wrapper:Wrapper"):
+    """Registers `<Scenario>-v0` like robotarium_gym/__init__.py:4-23 when gym/gymnasium exists.
+    Returns the list of ids registered (empty if no gym is installed)."""
+    try:
+        from gym.envs.registration import register
+    except Exception:  # noqa: BLE001
+        try:
+            from gymnasium.envs.registration import register
+        except Exception:  # noqa: BLE001
+            return []
+    ids = []
+    for name in SCENARIOS:
+        register(name + "-v0", entry_point=entry_point,
+                 kwargs={"env_name": name, "config_path": default_config_path(name)})
+        ids.append(name + "-v0")
+    return ids

@@ -71,6 +71,16 @@ static inline float FN(atan2)(float y, float x) {
     if (x < 0.0f) a = 3.1415927410125732421875f - a;
     return (y < 0.0f) ? -a : a;
 }
+/* rps wraps with theta = atan2(sin theta, cos theta) (Appendix A.4): the identity on (-pi, pi].
+ * In binary32 that round trip perturbs theta by ~1e-7 every sub-iteration; the float spec
+ * instead subtracts 2*pi (hi + lo) only when |theta| exceeds pi -- closer to the float64
+ * sequence it stands for (measured: tests/test_oracle_spec.py) and free of transcendentals. */
+static inline float FN(wrap)(float t) {
+    if (t > 3.1415927410125732421875f) t = (t - 6.283185482025146484375f) - (-1.74845553146951715462e-07f);
+    else if (t < -3.1415927410125732421875f) t = (t + 6.283185482025146484375f) + (-1.74845553146951715462e-07f);
+    return t;
+}
+#define WRAP(t) FN(wrap)(t)
 #define SINCOS(t, s, c) FN(sincos)((t), (s), (c))
 #define ATAN2(y, x) FN(atan2)((y), (x))
 #define SQRT(v) __builtin_sqrtf(v)
@@ -79,6 +89,7 @@ static inline float FN(atan2)(float y, float x) {
 #else
 #define SINCOS(t, s, c) do { *(s) = sin(t); *(c) = cos(t); } while (0)
 #define ATAN2(y, x) atan2((y), (x))
+#define WRAP(t) atan2(sin(t), cos(t))
 #define SQRT(v) sqrt(v)
 #define QP_RTOL 5e-12
 #define QP_MAX_SWEEPS 200
@@ -119,6 +130,9 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
     REAL r2 = R(p->safety_radius) * R(p->safety_radius);
     REAL ex[ORC_MAXN][ORC_MAXN], ey[ORC_MAXN][ORC_MAXN], beta[ORC_MAXN][ORC_MAXN], n2[ORC_MAXN][ORC_MAXN],
         mu[ORC_MAXN][ORC_MAXN];
+#if ORC_IS_F32
+    REAL rn2[ORC_MAXN][ORC_MAXN];
+#endif
     for (int i = 0; i < N; ++i)
         for (int j = i + 1; j < N; ++j) {
             REAL dx = xix[i] - xix[j], dy = xiy[i] - xiy[j];
@@ -130,6 +144,9 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
             ey[i][j] = dy;
             beta[i][j] = R(0.5) * b;
             n2[i][j] = R(2) * ee;
+#if ORC_IS_F32
+            if (n2[i][j] > R(0)) rn2[i][j] = R(1) / n2[i][j]; /* float spec: one division per pair per QP */
+#endif
             mu[i][j] = R(0);
         }
     /* "Threshold control inputs before QP" */
@@ -150,7 +167,11 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
                 if (!(i < j && j < N)) continue;
                 if (!(n2[i][j] > R(0))) continue;
                 REAL r = ex[i][j] * (ux[j] - ux[i]) + ey[i][j] * (uy[j] - uy[i]) - beta[i][j];
+#if ORC_IS_F32
+                REAL d = r * rn2[i][j];
+#else
                 REAL d = r / n2[i][j];
+#endif
                 REAL mn = mu[i][j] + d;
                 if (!(mn > R(0))) mn = R(0);
                 REAL delta = mn - mu[i][j];
@@ -244,7 +265,11 @@ static int FN(validate)(const orc_params *p, int N, const REAL *x, const REAL *y
     for (int j = 0; j < N - 1; ++j)
         for (int k = j + 1; k < N; ++k) {
             REAL dx = fx[j] - fx[k], dy = fy[j] - fy[k];
+#if ORC_IS_F32
+            if (dx * dx + dy * dy <= lim * lim) code |= 1; /* float spec: squared form, no sqrt per pair */
+#else
             if (SQRT(dx * dx + dy * dy) <= lim) code |= 1;
+#endif
         }
     return code;
 }
@@ -344,9 +369,7 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
             x[a] = x[a] + dt * c * v[a];
             y[a] = y[a] + dt * s * v[a];
             REAL t = th[a] + dt * w[a];
-            REAL s2, c2;
-            SINCOS(t, &s2, &c2);
-            th[a] = ATAN2(s2, c2);
+            th[a] = WRAP(t);
         }
         if (p->penalize_violations && code) { /* roboEnv.py:82-94 */
             viol = code;
@@ -593,6 +616,7 @@ int FN(orc_controller)(const orc_params *p, const REAL *poses /*3xN*/, const REA
 
 #undef SINCOS
 #undef ATAN2
+#undef WRAP
 #undef SQRT
 #undef QP_RTOL
 #undef QP_MAX_SWEEPS

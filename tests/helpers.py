@@ -1,0 +1,48 @@
+"""Shared test helpers: golden fixtures, oracle envs, GPU envs loaded from the same state."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STATE_KEYS = ("poses", "carry", "steps", "prey_loc", "prey_sensed", "prey_captured", "loaded", "load",
+              "zone_load", "messages")
+GPU_NAME = {"carry": "carry_dist", "steps": "episode_steps"}
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(path):
+    g = np.load(path)
+    return g, str(g["scenario"]), json.loads(str(g["config_json"]))
+
+
+def pre_state(g):
+    return {k: g["pre_" + k] for k in STATE_KEYS if "pre_" + k in g.files}
+
+
+def oracle_from_state(c_oracle, scenario, cfg, state, dtype):
+    """One oracle env per fixture row, loaded with the row's pre-step state."""
+    T = len(state["poses"])
+    env = c_oracle.OracleVecEnv(scenario, cfg, T, dtype=dtype)
+    for k, v in state.items():
+        arr = getattr(env, k)
+        arr[...] = np.asarray(v).astype(arr.dtype).reshape(arr.shape)
+    return env
+
+
+def gpu_from_state(scenario, cfg, state, **kw):
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    T = len(state["poses"])
+    env = VecRobotariumEnv(scenario, T, overrides=cfg, auto_reset=False, collect_qp_stats=True, **kw)
+    sd = {GPU_NAME.get(k, k): torch.as_tensor(np.asarray(v)) for k, v in state.items()}
+    env.load_state_dict(sd)
+    return env
+
+
+def angle_diff(a, b):
+    return np.abs(np.angle(np.exp(1j * (np.asarray(a, np.float64) - np.asarray(b, np.float64)))))
