@@ -67,6 +67,10 @@ typedef struct rg_scenario_params {
     float collision_offset, collision_diameter;
     float projection_distance, angular_velocity_limit, position_velocity_limit;
     float barrier_gain, unsafe_barrier_gain, safety_radius, barrier_magnitude_limit;
+    /* barrier QP solver (sim_spec_v0: Hildreth sweeps): stop when the largest change of a sweep is
+     * <= qp_rtol * max(|u|_inf, barrier_magnitude_limit), or after qp_max_sweeps sweeps */
+    float qp_rtol;
+    int32_t qp_max_sweeps;
     /* scenario */
     float left, right, up, down;
     float agent_step[RG_MAX_AGENTS];     /* step_dist, or MaterialTransport per-agent speed */
@@ -78,6 +82,7 @@ typedef struct rg_scenario_params {
     /* reset (misc.py:49-63, scenario reset()) */
     rg_grid agent_grid, prey_grid;
     int32_t keep_theta;              /* Warehouse keeps the sampled heading, misc.py:58,62 zero it */
+    int32_t shared_reward;           /* config key: episode return adds reward[0] (1) or sum(reward) (0), misc.py:178-181 */
     float zone1_mean, zone1_std, zone2_mean, zone2_std; /* MaterialTransport.py:99-100 */
 } rg_scenario_params;
 
@@ -97,6 +102,12 @@ typedef struct rg_state {
     int32_t *load;          /* [E][N]      MaterialTransport */
     int32_t *zone_load;     /* [E][2] */
     int32_t *messages;      /* [E][4] */
+    /* Optional rollout statistics (all four NULL, or all four set), the on-device form of the
+     * accumulators in utilities/misc.py:151-206 (episodeReward, episodeSteps, totalReward): */
+    float *ep_return;       /* [E] return of the running episode */
+    float *done_return_sum; /* [E] sum of the returns of the episodes this env has finished */
+    int32_t *done_count;    /* [E] number of episodes this env has finished */
+    int32_t *done_steps_sum;/* [E] total length of those episodes */
 } rg_state;
 
 /* Everything Wrapper.step returns (wrapper.py:41-44), batched. */

@@ -35,7 +35,7 @@ class RgScenarioParams(C.Structure):
         ("projection_distance", C.c_float), ("angular_velocity_limit", C.c_float),
         ("position_velocity_limit", C.c_float),
         ("barrier_gain", C.c_float), ("unsafe_barrier_gain", C.c_float), ("safety_radius", C.c_float),
-        ("barrier_magnitude_limit", C.c_float),
+        ("barrier_magnitude_limit", C.c_float), ("qp_rtol", C.c_float), ("qp_max_sweeps", C.c_int32),
         ("left", C.c_float), ("right", C.c_float), ("up", C.c_float), ("down", C.c_float),
         ("agent_step", C.c_float * MAX_AGENTS), ("sensing_radius", C.c_float * MAX_AGENTS),
         ("capture_radius", C.c_float * MAX_AGENTS),
@@ -44,7 +44,7 @@ class RgScenarioParams(C.Structure):
         ("load_reward", C.c_float), ("unload_reward", C.c_float), ("goal_width", C.c_float),
         ("unload_multiplier", C.c_float), ("load_multiplier", C.c_float), ("end_goal_width", C.c_float),
         ("zone1_radius", C.c_float),
-        ("agent_grid", RgGrid), ("prey_grid", RgGrid), ("keep_theta", C.c_int32),
+        ("agent_grid", RgGrid), ("prey_grid", RgGrid), ("keep_theta", C.c_int32), ("shared_reward", C.c_int32),
         ("zone1_mean", C.c_float), ("zone1_std", C.c_float), ("zone2_mean", C.c_float),
         ("zone2_std", C.c_float),
     ]
@@ -54,7 +54,8 @@ class RgState(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("carry_dist", C.c_void_p), ("episode_steps", C.c_void_p),
                 ("reset_count", C.c_void_p), ("prey_loc", C.c_void_p), ("prey_sensed", C.c_void_p),
                 ("prey_captured", C.c_void_p), ("loaded", C.c_void_p), ("load", C.c_void_p),
-                ("zone_load", C.c_void_p), ("messages", C.c_void_p)]
+                ("zone_load", C.c_void_p), ("messages", C.c_void_p), ("ep_return", C.c_void_p),
+                ("done_return_sum", C.c_void_p), ("done_count", C.c_void_p), ("done_steps_sum", C.c_void_p)]
 
 
 class RgStepIO(C.Structure):

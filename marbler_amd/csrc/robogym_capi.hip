@@ -36,6 +36,7 @@ static int check_params(const rg_scenario_params *p) {
     if (p->n_agents < 1 || p->n_agents > RG_MAX_AGENTS) return fail(-3, "n_agents must be in 1..16");
     if (p->update_frequency < 1 || p->controller_period < 1) return fail(-4, "update_frequency / controller_period < 1");
     if (p->obs_dim < 1) return fail(-5, "obs_dim < 1");
+    if (p->qp_max_sweeps < 1 || !(p->qp_rtol >= 0.0f)) return fail(-5, "qp_max_sweeps < 1 or qp_rtol < 0");
     if (p->collision_variant != RG_COLLISION_CENTER && p->collision_variant != RG_COLLISION_OFFSET)
         return fail(-6, "unknown collision_variant");
     const rg_grid &g = p->agent_grid;
@@ -122,6 +123,9 @@ int rg_bind_state(rg_handle *h, const rg_state *st) {
             if (!st->load || !st->zone_load || !st->messages)
                 return fail(-21, "MaterialTransport needs load, zone_load, messages");
     }
+    const int nstat = (st->ep_return != nullptr) + (st->done_return_sum != nullptr) + (st->done_count != nullptr) +
+                      (st->done_steps_sum != nullptr);
+    if (nstat != 0 && nstat != 4) return fail(-25, "rollout statistics arrays: set all four or none");
     h->state = *st;
     h->bound = true;
     return 0;

@@ -57,6 +57,13 @@ __device__ __forceinline__ float xor_lane(float v) {
     else return dpp_f<QP1>(dpp_f<MIRROR>(v));
 }
 
+template <int K>
+__device__ __forceinline__ int xor_lane_i(int v) {
+    return __builtin_bit_cast(int, xor_lane<K>(__builtin_bit_cast(float, v)));
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
 template <int I, int END, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < END) {
@@ -65,13 +72,13 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// max over the lanes of a group (butterfly over xor 1, 2, 4, 8)
+// max over the lanes of a group (butterfly; every stage is a single DPP permute)
 template <int GW>
 __device__ __forceinline__ float group_max(float v) {
     v = fmaxf(v, xor_lane<1>(v));
     v = fmaxf(v, xor_lane<2>(v));
-    if constexpr (GW >= 8) v = fmaxf(v, xor_lane<4>(v));
-    if constexpr (GW >= 16) v = fmaxf(v, xor_lane<8>(v));
+    if constexpr (GW >= 8) v = fmaxf(v, xor_lane<7>(v));    // quads {0-3} <-> {4-7}: one row_half_mirror
+    if constexpr (GW >= 16) v = fmaxf(v, xor_lane<15>(v));  // halves of the row: one row_mirror
     return v;
 }
 
@@ -83,8 +90,6 @@ __device__ __forceinline__ bool group_any(bool pred, int gbase) {
     return ((m >> gbase) & GM) != 0ull;
 }
 
-constexpr float QP_RTOL = 1.25e-6f;
-constexpr int QP_MAX_SWEEPS = 40;
 
 struct Consts {  // derived scalars, computed in binary32 in the same form as the oracle
     float dt, pd, inv_pd, r2, wlim, vmax, wmax, pvl, bml;
@@ -124,39 +129,38 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     float ux = gx - xix, uy = gy - xiy;
     {
         const float nrm = norm2_spec(ux, uy);
-        if (nrm > k.pvl) {
-            const float sc = k.pvl / nrm;
-            ux = ux * sc;
-            uy = uy * sc;
-        }
+        const float sc = k.pvl / nrm;
+        const bool clip = nrm > k.pvl;
+        ux = clip ? ux * sc : ux;
+        uy = clip ? uy * sc : uy;
     }
     // a6 barrier certificate: rows e_ij.(u_j - u_i) <= beta_ij, one per round
+    const float bgain = p.barrier_gain, ugain = p.unsafe_barrier_gain, qp_rtol = p.qp_rtol;
+    const int qp_cap = p.qp_max_sweeps;
+    const bool has_unsafe = p.barrier_has_unsafe_gain != 0;
     float ex[GW - 1], ey[GW - 1], beta[GW - 1], rn2[GW - 1], mu[GW - 1];
-    bool pok[GW - 1];
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
         const float pxi = xor_lane<K>(xix), pyi = xor_lane<K>(xiy);
         const float dx = xix - pxi, dy = xiy - pyi;
         const float ee = dx * dx + dy * dy;
         const float h = ee - k.r2;
-        const float gain = (h >= 0.0f || !p.barrier_has_unsafe_gain) ? p.barrier_gain : p.unsafe_barrier_gain;
+        const float gain = ((h >= 0.0f) | !has_unsafe) ? bgain : ugain;
         const float b = gain * ((h * h) * h);
         const float n2 = 2.0f * ee;
-        const bool ok = lane_ok && ((ag ^ K) < N) && (n2 > 0.0f);
+        const bool ok = lane_ok & ((ag ^ K) < N) & (n2 > 0.0f);
         ex[K - 1] = dx;
         ey[K - 1] = dy;
         beta[K - 1] = 0.5f * b;
         rn2[K - 1] = ok ? 1.0f / n2 : 0.0f;
         mu[K - 1] = 0.0f;
-        pok[K - 1] = ok;
     });
     {   // "Threshold control inputs before QP"
         const float nrm = norm2_spec(ux, uy);
-        if (nrm > k.bml) {
-            const float sc = k.bml / nrm;
-            ux = ux * sc;
-            uy = uy * sc;
-        }
+        const float sc = k.bml / nrm;
+        const bool clip = nrm > k.bml;
+        ux = clip ? ux * sc : ux;
+        uy = clip ? uy * sc : uy;
     }
     // Hildreth sweeps; a group drops out when converged, the wave loops while any group is active
     bool active = upd;
@@ -165,38 +169,38 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         float chg = 0.0f;
         static_for<1, GW>([&](auto KK) {
             constexpr int K = decltype(KK)::value;
+            // rn2 is 0 for absent pairs and mu starts at 0, so they are no-ops; a converged group is
+            // frozen by zeroing its step (d = 0 -> mn = mu -> delta = 0): same arithmetic as the oracle
             const float pux = xor_lane<K>(ux), puy = xor_lane<K>(uy);
             const float r = ex[K - 1] * (pux - ux) + ey[K - 1] * (puy - uy) - beta[K - 1];
-            const float d = r * rn2[K - 1];
+            const float d = r * (active ? rn2[K - 1] : 0.0f);
             float mn = mu[K - 1] + d;
-            if (!(mn > 0.0f)) mn = 0.0f;
-            const float delta = (active && pok[K - 1]) ? (mn - mu[K - 1]) : 0.0f;
-            if (active && pok[K - 1]) mu[K - 1] = mn;
+            mn = (mn > 0.0f) ? mn : 0.0f;
+            const float delta = mn - mu[K - 1];
+            mu[K - 1] = mn;
             const float cx = delta * ex[K - 1], cy = delta * ey[K - 1];
             ux = ux + cx;
             uy = uy + cy;
             chg = fmaxf(chg, fmaxf(__builtin_fabsf(cx), __builtin_fabsf(cy)));
         });
         ++sweeps;
-        if (active) my_sweeps = sweeps;
+        my_sweeps = active ? sweeps : my_sweeps;
         const float um = lane_ok ? fmaxf(__builtin_fabsf(ux), __builtin_fabsf(uy)) : 0.0f;
         const float gchg = group_max<GW>(chg);
         const float gum = fmaxf(k.bml, group_max<GW>(um));
-        active = active && (gchg > QP_RTOL * gum) && (sweeps < QP_MAX_SWEEPS);
+        active = active & (gchg > qp_rtol * gum) & (sweeps < qp_cap);
     }
     // a7 si_to_uni_dyn, a8 set_velocities
     float vv = c * ux + s * uy;
     float ww = k.inv_pd * (-s * ux + c * uy);
-    if (ww > k.wlim) ww = k.wlim;
-    if (ww < -k.wlim) ww = -k.wlim;
-    if (vv > k.vmax) vv = k.vmax;
-    if (vv < -k.vmax) vv = -k.vmax;
-    if (ww > k.wmax) ww = k.wmax;
-    if (ww < -k.wmax) ww = -k.wmax;
-    if (upd) {
-        v = vv;
-        w = ww;
-    }
+    ww = ww > k.wlim ? k.wlim : ww;
+    ww = ww < -k.wlim ? -k.wlim : ww;
+    vv = vv > k.vmax ? k.vmax : vv;
+    vv = vv < -k.vmax ? -k.vmax : vv;
+    ww = ww > k.wmax ? k.wmax : ww;
+    ww = ww < -k.wmax ? -k.wmax : ww;
+    v = upd ? vv : v;
+    w = upd ? ww : w;
     return my_sweeps;
 }
 
@@ -321,34 +325,35 @@ __device__ __forceinline__ void write_neighbour_obs(int N, int Knb, int ag, bool
     float d[GW - 1];
     float nb[GW - 1][OD];
     bool ok[GW - 1];
+    int rank[GW - 1];
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
         const float px = xor_lane<K>(x), py = xor_lane<K>(y);
         const float dx = px - x, dy = py - y;
         d[K - 1] = norm2_spec(dx, dy);
-        ok[K - 1] = lane_ok && ((ag ^ K) < N);
+        ok[K - 1] = lane_ok & ((ag ^ K) < N);
+        rank[K - 1] = 0;
 #pragma unroll
         for (int c = 0; c < OD; ++c) nb[K - 1][c] = xor_lane<K>(own[c]);
     });
     const bool all_others = Knb >= N - 1;
+    // rank of partner K among the valid partners: one comparison per unordered pair (Q < K)
+    static_for<2, GW>([&](auto KK) {
+        constexpr int K = decltype(KK)::value;
+        static_for<1, K>([&](auto QQ) {
+            constexpr int Q = decltype(QQ)::value;
+            // is Q ahead of K?  distance first, then the lower agent index
+            const bool q_first = (d[Q - 1] < d[K - 1]) | ((d[Q - 1] == d[K - 1]) & ((ag ^ Q) < (ag ^ K)));
+            const bool both = ok[Q - 1] & ok[K - 1];
+            rank[K - 1] += (both & q_first) ? 1 : 0;
+            rank[Q - 1] += (both & !q_first) ? 1 : 0;
+        });
+    });
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
         const int j = ag ^ K;
-        int slot;
-        if (all_others) {
-            slot = j < ag ? j : j - 1;
-        } else {
-            int rank = 0;
-            static_for<1, GW>([&](auto QQ) {
-                constexpr int Q = decltype(QQ)::value;
-                if constexpr (Q != K) {
-                    const int jq = ag ^ Q;
-                    if (ok[Q - 1] && (d[Q - 1] < d[K - 1] || (d[Q - 1] == d[K - 1] && jq < j))) ++rank;
-                }
-            });
-            slot = rank;
-        }
-        if (ok[K - 1] && (all_others || slot < Knb)) {
+        const int slot = all_others ? (j < ag ? j : j - 1) : rank[K - 1];
+        if (ok[K - 1] & (all_others | (slot < Knb))) {
             float *o = obs_row + (slot + 1) * OD;
 #pragma unroll
             for (int c = 0; c < OD; ++c) o[c] = nb[K - 1][c];
@@ -426,50 +431,91 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 gy = clamp_spec(gy, p.up, p.down);
             }
         }
-        // ---- a2 roboEnv.step: U sub-iterations (utilities/roboEnv.py:52-94)
-        float px = x, py = y, v = 0.0f, w = 0.0f;
-        bool alive = env_ok;  // group-uniform: false once the env hit a violation
-        const int U = p.update_frequency;
-        int until_ctrl = 0;  // controller when it % controller_period == 0 (roboEnv.py:63)
-        for (int it = 0; it < U; ++it) {
-            if (alive) {  // dist_travelled lags one iteration (roboEnv.py:55-59)
-                dist = dist + (it == 0 ? carry : norm2_spec(x - px, y - py));
-                px = x;
-                py = y;
-            }
-            float s, c;
+        // ---- a2 roboEnv.step (utilities/roboEnv.py:52-94), float spec of oracle/oracle_core.h, one
+        // CONTROLLER PERIOD (<= 15 sub-steps with v, w held) at a time: theta and dist_travelled
+        // advance once per period by fma; inside the period only x, y and (cos, sin) move.
+        //
+        // _validate every sub-step: the exact test (7 DPP rounds of float math) runs only in a rare
+        // wave-uniform branch.  The common path is a conservative integer pre-test on positions
+        // quantised to int16 pairs (4 m <-> 32767, LSB 0.12 mm): one DPP + v_pk_sub_i16 + v_dot2 per
+        // pair round, with a 4 LSB margin on the distance so it can never miss a collision the float
+        // test would flag.  Absent lanes / finished envs sit on far-apart ghost points.
+        const float lim = __builtin_sqrtf(k.coll_lim2);
+        const float lq = __builtin_fmaf(lim, 8191.75f, 4.0f);
+        const int thr_q = static_cast<int>(lq * lq) + 1;
+        const int ghost_q = (32767 & 0xFFFF) | (((-28000 + 3500 * ag) & 0xFFFF) << 16);  // >= 0.43 m apart, > 2 m from the arena
+        float v = 0.0f, w = 0.0f, s = 0.0f, c = 1.0f;
+        float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
+        bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
+        float fin_x = 0.0f, fin_y = 0.0f;
+        const bool penalize = p.penalize_violations != 0;
+        const int U = p.update_frequency, period = p.controller_period;
+        for (int it0 = 0; it0 < U; it0 += period) {
+            const int n = (U - it0) < period ? (U - it0) : period;
             sincos_spec(th, s, c);
-            if (until_ctrl == 0) {
-                const int sw = controller<GW>(p, k, N, ag, lane_ok, alive, x, y, c, s, gx, gy, v, w);
-                max_sweeps = sw > max_sweeps ? sw : max_sweeps;
-                until_ctrl = p.controller_period;
-            }
-            --until_ctrl;
-            // a10 _validate on the pre-update poses
-            const bool bnd = lane_ok && (x < k.xmin || x > k.xmax || y < k.ymin || y > k.ymax);
-            const float fx = x + k.coll_off * c, fy = y + k.coll_off * s;
-            bool col = false;
-            static_for<1, GW>([&](auto KK) {
-                constexpr int K = decltype(KK)::value;
-                const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
-                col = col || (((ag ^ K) < N) && (dx * dx + dy * dy <= k.coll_lim2));
-            });
-            col = col && lane_ok;
-            const int code = (group_any<GW>(col, gbase) ? 1 : 0) | (group_any<GW>(bnd, gbase) ? 2 : 0);
-            // Euler step + heading wrap (Appendix A.4)
-            if (alive) {
-                x = x + k.dt * c * v;
-                y = y + k.dt * s * v;
-                th = wrap_spec(th + k.dt * w);
-                if (p.penalize_violations && code) {  // roboEnv.py:92-94
-                    viol = code;
-                    dist = dist + norm2_spec(x - px, y - py);
-                    alive = false;
+            const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w);
+            max_sweeps = sw > max_sweeps ? sw : max_sweeps;
+            const float dtv = k.dt * v, dtw = k.dt * w;
+            float sd, cd;
+            sincos_spec(dtw, sd, cd);
+            int n_exec = n;           // sub-steps this env executes in this period
+            bool died_now = false;
+            for (int j = 0; j < n; ++j) {
+                // a10 _validate on the pre-update poses
+                const bool bnd = lane_ok & !dead & ((x < k.xmin) | (x > k.xmax) | (y < k.ymin) | (y > k.ymax));
+                const float fx = __builtin_fmaf(k.coll_off, c, x), fy = __builtin_fmaf(k.coll_off, s, y);
+                const int q_real = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pknorm_i16(fx * 0.25f, fy * 0.25f));
+                const int q = (lane_ok & !dead) ? q_real : ghost_q;
+                int dmin = 0x7FFFFFFF;
+                static_for<1, GW>([&](auto KK) {
+                    constexpr int K = decltype(KK)::value;
+                    const short2v dq = __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, q),
+                                                                     __builtin_bit_cast(short2v, xor_lane_i<K>(q)));
+                    const int d2 = __builtin_amdgcn_sdot2(dq, dq, 0, false);
+                    dmin = d2 < dmin ? d2 : dmin;
+                });
+                const bool near = dmin <= thr_q;
+                if (penalize && __any(near | bnd)) {  // rare: exact float test (roboEnv.py:82-94)
+                    bool col = false;
+                    static_for<1, GW>([&](auto KK) {
+                        constexpr int K = decltype(KK)::value;
+                        const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
+                        col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
+                    });
+                    col = col & lane_ok & !dead;
+                    const int code = (group_any<GW>(col, gbase) ? 1 : 0) | (group_any<GW>(bnd, gbase) ? 2 : 0);
+                    if (env_ok & !dead & (code != 0)) {
+                        viol = code;
+                        n_exec = j + 1;
+                        died_now = true;
+                        dead = true;
+                        fin_x = __builtin_fmaf(c, dtv, x);  // this sub-step is still integrated
+                        fin_y = __builtin_fmaf(s, dtv, y);
+                    }
                 }
+                // Euler step (Appendix A.4); rotate (cos, sin) by dt*w
+                x = __builtin_fmaf(c, dtv, x);
+                y = __builtin_fmaf(s, dtv, y);
+                const float cn = __builtin_fmaf(c, cd, -(s * sd));
+                const float sn = __builtin_fmaf(s, cd, c * sd);
+                c = cn;
+                s = sn;
             }
-            if (!__any(alive)) break;
+            // period end: heading and distance for the sub-steps this env executed
+            const bool upd = env_ok & (!dead | died_now);
+            const float ne = static_cast<float>(n_exec);
+            const float adv = __builtin_fabsf(dtv);
+            th = upd ? wrap_spec(__builtin_fmaf(ne, dtw, th)) : th;
+            acc = upd ? __builtin_fmaf(ne, adv, acc) : acc;
+            last = upd ? adv : last;
+            if (!__any(env_ok & !dead)) break;
         }
-        carry = norm2_spec(x - px, y - py);
+        if (dead) {
+            x = fin_x;
+            y = fin_y;
+        }
+        dist = viol ? acc : acc - last;
+        carry = last;
     }
 
     __syncthreads();  // LDS prey block visible (single-wave workgroup: compiles to waitcnt + s_barrier)
@@ -667,6 +713,13 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     }
 
     if constexpr (!OBS_ONLY) {
+        // sum of the agents' rewards in agent order (only read when shared_reward == 0)
+        float rsum = 0.0f;
+        if (a.st.ep_return && !p.shared_reward) {
+            lds.ax[lane] = lane_ok ? reward : 0.0f;
+            __syncthreads();
+            for (int j = 0; j < N; ++j) rsum = rsum + lds.ax[gbase + j];
+        }
         // ---- stores
         if (lane_ok) {
             float *X = a.st.poses + eN * 3;
@@ -678,6 +731,16 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             a.io.dist_travelled[eN + ag] = dist;
             if (ag == 0) {
                 a.st.episode_steps[e] = steps;
+                if (a.st.ep_return) {  // misc.py:178-185: episodeReward += reward[0] | sum(reward)
+                    float ret = a.st.ep_return[e] + (p.shared_reward ? reward : rsum);
+                    if (done) {
+                        a.st.done_return_sum[e] = a.st.done_return_sum[e] + ret;
+                        a.st.done_count[e] = a.st.done_count[e] + 1;
+                        a.st.done_steps_sum[e] = a.st.done_steps_sum[e] + steps;
+                        ret = 0.0f;
+                    }
+                    a.st.ep_return[e] = ret;
+                }
                 a.io.done[e] = done ? 1 : 0;
                 a.io.violation[e] = static_cast<uint8_t>(viol);
                 a.io.remaining[e] = remaining;

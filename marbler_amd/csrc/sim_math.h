@@ -37,11 +37,10 @@ __device__ __forceinline__ void sincos_spec(float t, float &s, float &c) {
 // rps wraps headings with atan2(sin t, cos t): the identity on (-pi, pi].  The float spec
 // subtracts 2*pi (hi + lo) only when |t| exceeds pi (see oracle/oracle_core.h).
 __device__ __forceinline__ float wrap_spec(float t) {
-    if (t > 3.1415927410125732421875f)
-        t = (t - 6.283185482025146484375f) - (-1.74845553146951715462e-07f);
-    else if (t < -3.1415927410125732421875f)
-        t = (t + 6.283185482025146484375f) + (-1.74845553146951715462e-07f);
-    return t;
+    const float dn = (t - 6.283185482025146484375f) - (-1.74845553146951715462e-07f);
+    const float up = (t + 6.283185482025146484375f) + (-1.74845553146951715462e-07f);
+    const float r = t < -3.1415927410125732421875f ? up : t;   // branch-free: selects, not exec masks
+    return t > 3.1415927410125732421875f ? dn : r;
 }
 
 __device__ __forceinline__ float norm2_spec(float dx, float dy) { return __builtin_sqrtf(dx * dx + dy * dy); }

@@ -1,0 +1,78 @@
+"""Multi-GPU: one process per GPU, envs sharded in contiguous blocks, no per-step exchange.
+
+The path shards trivially (envs are independent); the only collectives
+are a broadcast of the scenario parameter block from rank 0 at init and a gather of
+per-env episode statistics per reporting interval -- both through torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the world_size-2 tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from .params import params_from_bytes, params_to_bytes
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world_size, local_rank).  world_size 1: no process group is created."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard(total_envs, rank, world):
+    """Contiguous block of envs owned by `rank`: (offset, count).  Remainders go to low ranks."""
+    base, rem = divmod(total_envs, world)
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+def broadcast_params(params, src=0, device=None):
+    """Rank `src` sends its rg_scenario_params block (< 1 KB); every rank returns a copy of it."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return params
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+    if dist.get_rank() == src:
+        buf = torch.frombuffer(bytearray(params_to_bytes(params)), dtype=torch.uint8).to(device)
+    else:
+        import ctypes
+        from ._lib import RgScenarioParams
+        buf = torch.zeros(ctypes.sizeof(RgScenarioParams), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=src)
+    return params_from_bytes(buf.cpu().numpy().tobytes())
+
+
+def gather_episode_stats(done_return_sum, done_count, done_steps_sum, dst=0):
+    """Gathers the per-env [E_local] statistics of every rank to `dst` (fixed-size all_gather, as
+    the shards are equal up to one env).  Returns (returns [E_total], counts, steps) on dst,
+    None elsewhere.  With no process group: the inputs."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return done_return_sum, done_count, done_steps_sum
+    world = dist.get_world_size()
+    n = torch.tensor([done_return_sum.numel()], device=done_return_sum.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    m = int(max(s.item() for s in sizes))
+    packed = torch.zeros(3, m, dtype=torch.float32, device=done_return_sum.device)
+    k = done_return_sum.numel()
+    packed[0, :k] = done_return_sum
+    packed[1, :k] = done_count.float()
+    packed[2, :k] = done_steps_sum.float()
+    out = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(out, packed)
+    if dist.get_rank() != dst:
+        return None
+    cat = torch.cat([o[:, :int(s.item())] for o, s in zip(out, sizes)], dim=1)
+    return cat[0], cat[1].to(torch.int64), cat[2].to(torch.int64)

@@ -24,6 +24,12 @@ CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 # (roboEnv.py:84-86).  Override with config key `collision_variant: center`.
 DEFAULT_COLLISION_VARIANT = "offset"
 
+# sim_spec_v0 barrier-QP solver constants (float32): relative tolerance and sweep cap of the
+# Hildreth iteration that stands in for cvxopt's interior-point qp (which the reference runs at
+# reltol 1e-2).  Config keys `qp_rtol`, `qp_max_sweeps` override.
+QP_RTOL = 1.25e-6
+QP_MAX_SWEEPS = 40
+
 
 def default_config_path(scenario):
     return os.path.join(CONFIG_DIR, scenario + ".yaml")
@@ -73,6 +79,7 @@ def make_params(scenario, cfg):
     p.controller_period = 15                                   # roboEnv.py:63
     p.max_episode_steps = int(cfg["max_episode_steps"])
     p.penalize_violations = int(bool(cfg["penalize_violations"]))
+    p.shared_reward = int(bool(cfg.get("shared_reward", scenario != "Warehouse")))
     if cfg.get("robotarium", False) or cfg.get("real_time", False):
         raise ValueError("robotarium / real_time runs drive the physical testbed and are out of scope")
     bc = cfg.get("barrier_certificate", "safe")                # roboEnv.py:15-18
@@ -81,6 +88,8 @@ def make_params(scenario, cfg):
     p.barrier_has_unsafe_gain = 1 if bc == "safe" else 0       # controller.py:13-16
     p.safety_radius = 0.2 if bc == "safe" else 0.17
     p.barrier_gain, p.unsafe_barrier_gain, p.barrier_magnitude_limit = 100.0, 1e6, 0.2
+    p.qp_rtol = float(cfg.get("qp_rtol", QP_RTOL))
+    p.qp_max_sweeps = int(cfg.get("qp_max_sweeps", QP_MAX_SWEEPS))
     p.collision_variant = COLLISION_VARIANTS[cfg.get("collision_variant", DEFAULT_COLLISION_VARIANT)]
     p.time_step = 0.033
     p.bound_x0, p.bound_y0, p.bound_w, p.bound_h = -1.6, -1.0, 3.2, 2.0

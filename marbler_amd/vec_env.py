@@ -65,6 +65,11 @@ class VecRobotariumEnv(object):
         self.load = torch.zeros(E, N, dtype=i32, device=dev)
         self.zone_load = torch.zeros(E, 2, dtype=i32, device=dev)
         self.messages = torch.zeros(E, 4, dtype=i32, device=dev)
+        # ---- rollout statistics (misc.py:151-206 accumulators, on device)
+        self.ep_return = torch.zeros(E, dtype=f32, device=dev)
+        self.done_return_sum = torch.zeros(E, dtype=f32, device=dev)
+        self.done_count = torch.zeros(E, dtype=i32, device=dev)
+        self.done_steps_sum = torch.zeros(E, dtype=i32, device=dev)
         # ---- step outputs (rg_step_io)
         self.obs = torch.zeros(E, N, D, dtype=f32, device=dev)
         self.reward = torch.zeros(E, N, dtype=f32, device=dev)
@@ -81,7 +86,8 @@ class VecRobotariumEnv(object):
             raise _lib.RobogymError("rg_create failed: " + self.lib.rg_last_error().decode())
         st = _lib.RgState(*(t.data_ptr() for t in (
             self.poses, self.carry_dist, self.episode_steps, self.reset_count, self.prey_loc, self.prey_sensed,
-            self.prey_captured, self.loaded, self.load, self.zone_load, self.messages)))
+            self.prey_captured, self.loaded, self.load, self.zone_load, self.messages, self.ep_return,
+            self.done_return_sum, self.done_count, self.done_steps_sum)))
         _lib.check(self.lib.rg_bind_state(self._h, C.byref(st)), "rg_bind_state")
         self._io = _lib.RgStepIO(self.obs.data_ptr(), self.reward.data_ptr(), self.done_u8.data_ptr(),
                                  self.dist_travelled.data_ptr(), self.violation.data_ptr(),
@@ -152,6 +158,11 @@ class VecRobotariumEnv(object):
     def load_state_dict(self, sd):
         for k, v in sd.items():
             getattr(self, k).copy_(torch.as_tensor(v).to(getattr(self, k).dtype).reshape(getattr(self, k).shape))
+
+    def episode_stats(self):
+        """(sum of finished-episode returns, number of finished episodes, total steps in them) as
+        0-dim device tensors -- the quantities run_env prints per run (misc.py:219-221)."""
+        return self.done_return_sum.sum(), self.done_count.sum(), self.done_steps_sum.sum()
 
     def close(self):
         if getattr(self, "_h", None):

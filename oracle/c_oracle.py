@@ -31,7 +31,8 @@ class OrcParams(C.Structure):
         ("projection_distance", C.c_double), ("angular_velocity_limit", C.c_double),
         ("position_velocity_limit", C.c_double),
         ("barrier_gain", C.c_double), ("unsafe_barrier_gain", C.c_double), ("safety_radius", C.c_double),
-        ("barrier_magnitude_limit", C.c_double),
+        ("barrier_magnitude_limit", C.c_double), ("qp_rtol", C.c_double), ("qp_max_sweeps", C.c_int32),
+        ("pad_", C.c_int32),
         ("left", C.c_double), ("right", C.c_double), ("up", C.c_double), ("down", C.c_double),
         ("agent_step", C.c_double * MAXN), ("sensing_radius", C.c_double * MAXN),
         ("capture_radius", C.c_double * MAXN),
@@ -62,9 +63,15 @@ def lib():
     return _lib
 
 
-def params_from_config(scenario, cfg, collision_variant="offset"):
+QP_RTOL = {"float32": 1.25e-6, "float64": 5e-12}
+QP_MAX_SWEEPS = {"float32": 40, "float64": 200}
+
+
+def params_from_config(scenario, cfg, collision_variant="offset", dtype=np.float64):
     """YAML keys of the reference's scenario config.yaml -> orc_params (Appendix A/B constants)."""
     p = OrcParams()
+    p.qp_rtol = cfg.get("qp_rtol", QP_RTOL[np.dtype(dtype).name])
+    p.qp_max_sweeps = cfg.get("qp_max_sweeps", QP_MAX_SWEEPS[np.dtype(dtype).name])
     p.scenario = SCN[scenario]
     p.update_frequency = int(cfg["update_frequency"])
     p.controller_period = 15
@@ -134,7 +141,7 @@ class OracleVecEnv(object):
         self.scenario, self.cfg, self.E = scenario, dict(cfg), E
         self.dtype = np.dtype(dtype)
         assert self.dtype in (np.dtype(np.float64), np.dtype(np.float32))
-        self.p = params_from_config(scenario, cfg, collision_variant)
+        self.p = params_from_config(scenario, cfg, collision_variant, self.dtype)
         N, P, D = self.p.n_agents, self.p.num_prey, self.p.obs_dim
         self.N, self.P, self.D = N, P, D
         f = self.dtype
@@ -214,7 +221,7 @@ def spec_atan2_f32(y, x):
 
 def controller(scenario, cfg, poses, goals, dtype=np.float64, collision_variant="offset"):
     """a3-a8 for one env: poses 3xN, goals 2xN -> (dxu 2xN after set_velocities clipping, sweeps)."""
-    p = params_from_config(scenario, cfg, collision_variant)
+    p = params_from_config(scenario, cfg, collision_variant, dtype)
     f = np.dtype(dtype)
     ct = C.c_double if f == np.float64 else C.c_float
     poses = np.ascontiguousarray(poses, f)

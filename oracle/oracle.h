@@ -29,6 +29,8 @@ typedef struct orc_params {
     double collision_offset, collision_diameter;
     double projection_distance, angular_velocity_limit, position_velocity_limit;
     double barrier_gain, unsafe_barrier_gain, safety_radius, barrier_magnitude_limit;
+    double qp_rtol;               /* Hildreth stop: max change <= qp_rtol * max(|u|_inf, magnitude_limit) */
+    int32_t qp_max_sweeps, pad_;
     /* scenario */
     double left, right, up, down;
     double agent_step[ORC_MAXN];      /* step_dist, or MaterialTransport per-agent speed */

@@ -84,15 +84,11 @@ static inline float FN(wrap)(float t) {
 #define SINCOS(t, s, c) FN(sincos)((t), (s), (c))
 #define ATAN2(y, x) FN(atan2)((y), (x))
 #define SQRT(v) __builtin_sqrtf(v)
-#define QP_RTOL 1.25e-6f
-#define QP_MAX_SWEEPS 40
 #else
 #define SINCOS(t, s, c) do { *(s) = sin(t); *(c) = cos(t); } while (0)
 #define ATAN2(y, x) atan2((y), (x))
 #define WRAP(t) atan2(sin(t), cos(t))
 #define SQRT(v) sqrt(v)
-#define QP_RTOL 5e-12
-#define QP_MAX_SWEEPS 200
 #endif
 
 #define R(v) ((REAL)(v))
@@ -194,18 +190,17 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
             if (ax > umax) umax = ax;
             if (ay > umax) umax = ay;
         }
-        if (!(maxchg > QP_RTOL * umax) || sweeps >= QP_MAX_SWEEPS) break;
+        if (!(maxchg > R(p->qp_rtol) * umax) || sweeps >= p->qp_max_sweeps) break;
     }
     return sweeps;
 }
 
 /* a3 = a4 . a5 . a6 . a7, then a8 (utilities/controller.py:20-24, roboEnv.py:64-65) */
-static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *th, const REAL *gx,
-                          const REAL *gy, REAL *v, REAL *w) {
-    REAL cs[ORC_MAXN], ss[ORC_MAXN], xix[ORC_MAXN], xiy[ORC_MAXN], ux[ORC_MAXN], uy[ORC_MAXN];
+static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *cs, const REAL *ss,
+                          const REAL *gx, const REAL *gy, REAL *v, REAL *w) {
+    REAL xix[ORC_MAXN], xiy[ORC_MAXN], ux[ORC_MAXN], uy[ORC_MAXN];
     REAL pd = R(p->projection_distance);
     for (int a = 0; a < N; ++a) {
-        SINCOS(th[a], &ss[a], &cs[a]);
         xix[a] = x[a] + pd * cs[a]; /* a4 uni_to_si_states */
         xiy[a] = y[a] + pd * ss[a];
         REAL dx = gx[a] - xix[a], dy = gy[a] - xiy[a]; /* a5 si_position_controller, gain 1 */
@@ -239,7 +234,7 @@ static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL 
 }
 
 /* a10 _validate: returns bit0 collision, bit1 boundary */
-static int FN(validate)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *th) {
+static int FN(validate)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *cs, const REAL *ss) {
     int code = 0;
     REAL xmin = R(p->bound_x0), ymin = R(p->bound_y0);
     REAL xmax = xmin + R(p->bound_w), ymax = ymin + R(p->bound_h);
@@ -249,10 +244,13 @@ static int FN(validate)(const orc_params *p, int N, const REAL *x, const REAL *y
     REAL lim;
     if (p->collision_variant == 1) {
         for (int a = 0; a < N; ++a) {
-            REAL s, c;
-            SINCOS(th[a], &s, &c);
-            fx[a] = x[a] + R(p->collision_offset) * c;
-            fy[a] = y[a] + R(p->collision_offset) * s;
+#if ORC_IS_F32
+            fx[a] = __builtin_fmaf(R(p->collision_offset), cs[a], x[a]);
+            fy[a] = __builtin_fmaf(R(p->collision_offset), ss[a], y[a]);
+#else
+            fx[a] = x[a] + R(p->collision_offset) * cs[a];
+            fy[a] = y[a] + R(p->collision_offset) * ss[a];
+#endif
         }
         lim = R(p->collision_diameter);
     } else {
@@ -347,6 +345,64 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
     /* a2 roboEnv.step (utilities/roboEnv.py:38-96) */
     int viol = 0, max_sweeps = 0;
     REAL dt = R(p->time_step);
+    REAL cs[ORC_MAXN], ss[ORC_MAXN];
+#if ORC_IS_F32
+    /* float spec (sim_spec_v0), algebraically the same step as the float64 sequence below, arranged
+     * per CONTROLLER PERIOD (the <= 15 sub-steps during which v and w are held, roboEnv.py:63):
+     *  - the length of a sub-step is |dt*v| (= |P_k+1 - P_k| of the Euler update): no sqrt, and n
+     *    equal sub-steps add n*|dt*v| in one fma.  dist_travelled lags one sub-step
+     *    (roboEnv.py:55-59): dist = carry_in + sum of all sub-step lengths - the last one, which
+     *    becomes carry_out; on a violation the last one is included (roboEnv.py:93);
+     *  - theta advances n*dt*w in one fma and is wrapped once per period;
+     *  - within a period sin/cos of the heading advance by the rotation (cos, sin)(dt*w) instead
+     *    of being re-evaluated; x, y and the collision offset point use explicit fma. */
+    REAL acc[ORC_MAXN], dtv[ORC_MAXN], dtw[ORC_MAXN], cd[ORC_MAXN], sd[ORC_MAXN], last[ORC_MAXN];
+    for (int a = 0; a < N; ++a) {
+        acc[a] = st->carry[(size_t)e * N + a];
+        last[a] = R(0);
+    }
+    for (int it0 = 0; it0 < p->update_frequency && !viol; it0 += p->controller_period) {
+        int n = p->update_frequency - it0;
+        if (n > p->controller_period) n = p->controller_period;
+        for (int a = 0; a < N; ++a) SINCOS(th[a], &ss[a], &cs[a]);
+        int sw = FN(controller)(p, N, x, y, cs, ss, gx, gy, v, w);
+        if (sw > max_sweeps) max_sweeps = sw;
+        for (int a = 0; a < N; ++a) {
+            dtv[a] = dt * v[a];
+            dtw[a] = dt * w[a];
+            SINCOS(dtw[a], &sd[a], &cd[a]);
+        }
+        int n_exec = n;
+        for (int j = 0; j < n; ++j) {
+            int code = FN(validate)(p, N, x, y, cs, ss);
+            for (int a = 0; a < N; ++a) {
+                x[a] = __builtin_fmaf(cs[a], dtv[a], x[a]);
+                y[a] = __builtin_fmaf(ss[a], dtv[a], y[a]);
+                REAL cn = __builtin_fmaf(cs[a], cd[a], -(ss[a] * sd[a]));
+                REAL sn = __builtin_fmaf(ss[a], cd[a], cs[a] * sd[a]);
+                cs[a] = cn;
+                ss[a] = sn;
+            }
+            if (p->penalize_violations && code) {
+                viol = code;
+                n_exec = j + 1;
+                break;
+            }
+        }
+        for (int a = 0; a < N; ++a) {
+            last[a] = __builtin_fabsf(dtv[a]);
+            th[a] = WRAP(__builtin_fmaf((REAL)n_exec, dtw[a], th[a]));
+            acc[a] = __builtin_fmaf((REAL)n_exec, last[a], acc[a]);
+        }
+    }
+    for (int a = 0; a < N; ++a) {
+        X[a] = x[a];
+        Y[a] = y[a];
+        TH[a] = th[a];
+        st->carry[(size_t)e * N + a] = last[a];
+        out->dist[(size_t)e * N + a] = viol ? acc[a] : acc[a] - last[a];
+    }
+#else
     for (int it = 0; it < p->update_frequency; ++it) {
         for (int a = 0; a < N; ++a) {
             if (it == 0) {
@@ -358,16 +414,15 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
             px[a] = x[a];
             py[a] = y[a];
         }
+        for (int a = 0; a < N; ++a) SINCOS(th[a], &ss[a], &cs[a]);
         if (it % p->controller_period == 0) {
-            int s = FN(controller)(p, N, x, y, th, gx, gy, v, w);
+            int s = FN(controller)(p, N, x, y, cs, ss, gx, gy, v, w);
             if (s > max_sweeps) max_sweeps = s;
         }
-        int code = FN(validate)(p, N, x, y, th); /* rps step(): validate first ... */
-        for (int a = 0; a < N; ++a) {            /* ... then Euler + wrap (Appendix A.4) */
-            REAL s, c;
-            SINCOS(th[a], &s, &c);
-            x[a] = x[a] + dt * c * v[a];
-            y[a] = y[a] + dt * s * v[a];
+        int code = FN(validate)(p, N, x, y, cs, ss); /* rps step(): validate first ... */
+        for (int a = 0; a < N; ++a) {              /* ... then Euler + wrap (Appendix A.4) */
+            x[a] = x[a] + dt * cs[a] * v[a];
+            y[a] = y[a] + dt * ss[a] * v[a];
             REAL t = th[a] + dt * w[a];
             th[a] = WRAP(t);
         }
@@ -388,6 +443,7 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
         st->carry[(size_t)e * N + a] = SQRT(dx * dx + dy * dy);
         out->dist[(size_t)e * N + a] = dist[a];
     }
+#endif
     out->viol[e] = (uint8_t)viol;
     if (out->qp_sweeps) out->qp_sweeps[e] = max_sweeps;
     int steps = st->steps[e] + 1;
@@ -611,13 +667,13 @@ void FN(orc_atan2)(int n, const REAL *y, const REAL *x, REAL *o) {
 }
 int FN(orc_controller)(const orc_params *p, const REAL *poses /*3xN*/, const REAL *goals /*2xN*/, REAL *dxu /*2xN*/) {
     int N = p->n_agents;
-    return FN(controller)(p, N, poses, poses + N, poses + 2 * N, goals, goals + N, dxu, dxu + N);
+    REAL cs[ORC_MAXN], ss[ORC_MAXN];
+    for (int a = 0; a < N; ++a) SINCOS(poses[2 * N + a], &ss[a], &cs[a]);
+    return FN(controller)(p, N, poses, poses + N, cs, ss, goals, goals + N, dxu, dxu + N);
 }
 
 #undef SINCOS
 #undef ATAN2
 #undef WRAP
 #undef SQRT
-#undef QP_RTOL
-#undef QP_MAX_SWEEPS
 #undef R

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Kernel-time probe: per-launch time of rg_step under variations (sweep cap, auto-reset, E).
+Diagnostic only (not the judged bench)."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from marbler_amd import VecRobotariumEnv  # noqa: E402
+
+OV = {"PredatorCapturePrey": {"predator": 3, "capture": 2, "n_agents": 5},
+      "Warehouse": {"n_agents": 8},
+      "MaterialTransport": {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}}
+
+
+def probe(scenario, E, steps=400, warm=100, auto_reset=True, **over):
+    ov = dict(OV[scenario])
+    ov.update(over)
+    env = VecRobotariumEnv(scenario, E, overrides=ov, auto_reset=auto_reset, collect_qp_stats=True)
+    nact = 20 if scenario == "MaterialTransport" else 5
+    g = torch.Generator(device=env.device)
+    g.manual_seed(1)
+    acts = torch.randint(0, nact, (64, E, env.N), generator=g, device=env.device, dtype=torch.int32)
+    env.reset()
+    for i in range(warm):
+        env.step_raw(acts[i % 64].data_ptr())
+        if not auto_reset and i % 20 == 19:
+            env.reset(env.done_u8)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sw = torch.zeros(64, dtype=torch.int64, device=env.device)
+    a.record()
+    for i in range(steps):
+        env.step_raw(acts[i % 64].data_ptr())
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    # sweep statistics of the last step
+    q = env.qp_sweeps.float()
+    return {"scenario": scenario, "E": E, "auto_reset": auto_reset, "over": over, "us_per_step": ms * 1e3,
+            "agent_steps_per_s": E * env.N / (ms * 1e-3), "qp_sweeps_max": int(q.max().item()),
+            "qp_sweeps_mean": float(q.mean().item())}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--set", default="basic")
+    args = ap.parse_args()
+    out = []
+    if args.set == "basic":
+        for cap in (40, 16, 8, 4, 2, 1):
+            out.append(probe("PredatorCapturePrey", 4096, qp_max_sweeps=cap))
+        out.append(probe("PredatorCapturePrey", 4096, auto_reset=False))
+        for E in (8, 512, 2048, 8192, 32768, 131072, 524288):
+            out.append(probe("PredatorCapturePrey", E, steps=200 if E < 100000 else 50))
+        out.append(probe("Warehouse", 4096))
+        out.append(probe("MaterialTransport", 4096, steps=200))
+    for r in out:
+        print(json.dumps(r))
