@@ -232,3 +232,29 @@ def controller(scenario, cfg, poses, goals, dtype=np.float64, collision_variant=
     fn.restype = C.c_int
     sweeps = fn(C.byref(p), _ptr(poses, ct), _ptr(goals, ct), _ptr(dxu, ct))
     return dxu, sweeps
+
+
+class OrcGrid(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("spacing", C.c_float), ("w2", C.c_float),
+                ("h2", C.c_float), ("ox1", C.c_float), ("ox2", C.c_float), ("oy1", C.c_float),
+                ("oy2", C.c_float)]
+
+
+class OrcResetParams(C.Structure):
+    _fields_ = [("scenario", C.c_int32), ("n_agents", C.c_int32), ("num_prey", C.c_int32),
+                ("keep_theta", C.c_int32), ("agent_grid", OrcGrid), ("prey_grid", OrcGrid),
+                ("zone1_mean", C.c_float), ("zone1_std", C.c_float), ("zone2_mean", C.c_float),
+                ("zone2_std", C.c_float)]
+
+
+def reset_env_f32(rp, seed, global_env, episode):
+    """The float-spec reset sampler for one env: returns (poses [3,N], prey_loc [P,2], zone_load [2])."""
+    N, P = rp.n_agents, max(rp.num_prey, 1)
+    poses = np.zeros((3, N), np.float32)
+    prey = np.zeros((P, 2), np.float32)
+    zone = np.zeros(2, np.int32)
+    fn = lib().orc_reset_env_f32
+    fn.restype = None
+    fn(C.byref(rp), C.c_uint64(seed), C.c_uint64(global_env), C.c_uint32(episode), _ptr(poses, C.c_float),
+       _ptr(prey, C.c_float), _ptr(zone, C.c_int32))
+    return poses, prey, zone

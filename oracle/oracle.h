@@ -41,4 +41,17 @@ typedef struct orc_params {
     double unload_multiplier, load_multiplier, end_goal_width, zone1_radius;
 } orc_params;
 
+/* reset sampler (a17) of sim_spec_v0: grid geometry as the host computes it in float64 from the
+ * reference's formulas (misc.py:49-63, warehouse.py:93-98), already rounded to float */
+typedef struct orc_grid {
+    int32_t nx, ny;
+    float spacing, w2, h2, ox1, ox2, oy1, oy2;
+} orc_grid;
+
+typedef struct orc_reset_params {
+    int32_t scenario, n_agents, num_prey, keep_theta;
+    orc_grid agent_grid, prey_grid;
+    float zone1_mean, zone1_std, zone2_mean, zone2_std;
+} orc_reset_params;
+
 #endif

@@ -343,6 +343,9 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
         gy[a] = ty;
     }
     /* a2 roboEnv.step (utilities/roboEnv.py:38-96) */
+    (void)px;
+    (void)py;
+    (void)dist;
     int viol = 0, max_sweeps = 0;
     REAL dt = R(p->time_step);
     REAL cs[ORC_MAXN], ss[ORC_MAXN];

@@ -46,3 +46,17 @@ def gpu_from_state(scenario, cfg, state, **kw):
 
 def angle_diff(a, b):
     return np.abs(np.angle(np.exp(1j * (np.asarray(a, np.float64) - np.asarray(b, np.float64)))))
+
+
+def oracle_reset_params(c_oracle, rg_params):
+    """orc_reset_params from the product's rg_scenario_params (same float values)."""
+    rp = c_oracle.OrcResetParams()
+    rp.scenario, rp.n_agents, rp.num_prey, rp.keep_theta = \
+        rg_params.scenario, rg_params.n_agents, rg_params.num_prey, rg_params.keep_theta
+    for name in ("agent_grid", "prey_grid"):
+        src, dst = getattr(rg_params, name), getattr(rp, name)
+        for f, _ in c_oracle.OrcGrid._fields_:
+            setattr(dst, f, getattr(src, f))
+    rp.zone1_mean, rp.zone1_std = rg_params.zone1_mean, rg_params.zone1_std
+    rp.zone2_mean, rp.zone2_std = rg_params.zone2_mean, rg_params.zone2_std
+    return rp

@@ -1,0 +1,103 @@
+"""Device reset (a17) on the GPU: bit-exact against the oracle's sampler twin, invariant to how
+envs are sharded, and with the reference's geometry (grid cells, no two robots in one cell)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_reset_params
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}),
+         ("PredatorCapturePrey", {}),
+         ("Warehouse", {"n_agents": 8}),
+         ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}),
+         ("MaterialTransport", {})]
+
+
+@pytest.mark.parametrize("scenario,ov", CASES)
+def test_reset_bit_exact_and_shard_invariant(scenario, ov, oracle_lib):
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    E, seed = 300, 0x1234567890ABCDEF
+    env = VecRobotariumEnv(scenario, E, overrides=ov, seed=seed)
+    env.reset()
+    env.reset(torch.arange(E, device=env.device) % 3 == 0)      # second episode for a third of the envs
+    torch.cuda.synchronize()
+    poses, prey, zone = env.poses.cpu().numpy(), env.prey_loc.cpu().numpy(), env.zone_load.cpu().numpy()
+    rc = env.reset_count.cpu().numpy()
+    assert np.array_equal(rc, 1 + (np.arange(E) % 3 == 0))
+    rp = oracle_reset_params(oracle_lib, env.params)
+    for e in range(E):
+        p, q, z = oracle_lib.reset_env_f32(rp, seed, e, int(rc[e]) - 1)
+        assert np.array_equal(poses[e].view(np.uint32), p.view(np.uint32)), e
+        if scenario == "PredatorCapturePrey":
+            assert np.array_equal(prey[e].view(np.uint32), q.view(np.uint32)), e
+        if scenario == "MaterialTransport":
+            assert np.array_equal(zone[e], z), e
+    # the same global envs from a shard with an offset
+    env2 = VecRobotariumEnv(scenario, 100, overrides=ov, seed=seed, env_offset=150)
+    env2.reset()
+    torch.cuda.synchronize()
+    first = VecRobotariumEnv(scenario, E, overrides=ov, seed=seed)
+    first.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(env2.poses, first.poses[150:250])
+    assert torch.equal(env2.prey_loc, first.prey_loc[150:250])
+    assert torch.equal(env2.zone_load, first.zone_load[150:250])
+    for x in (env, env2, first):
+        x.close()
+
+
+@pytest.mark.parametrize("scenario,ov", CASES)
+def test_reset_geometry_and_state(scenario, ov):
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    E = 4096
+    env = VecRobotariumEnv(scenario, E, overrides=ov, seed=7)
+    env.carry_dist.fill_(3.0)
+    env.episode_steps.fill_(9)
+    env.loaded.fill_(1)
+    env.load.fill_(5)
+    env.prey_sensed.fill_(1)
+    env.messages.fill_(3)
+    obs = env.reset()
+    torch.cuda.synchronize()
+    assert float(obs.abs().max()) == 0.0                        # reference returns zeros from reset()
+    assert int(env.episode_steps.abs().max()) == 0 and float(env.carry_dist.abs().max()) == 0.0
+    if scenario == "PredatorCapturePrey":
+        assert int(env.prey_sensed.max()) == 0
+    if scenario == "Warehouse":
+        assert int(env.loaded.max()) == 0
+    if scenario == "MaterialTransport":
+        assert int(env.load.max()) == 0 and int(env.messages.max()) == 0
+    g = env.params.agent_grid
+    P = env.poses.double().cpu().numpy()
+    cx = (P[:, 0] - g.ox1 - g.ox2 + g.w2) / g.spacing
+    cy = (P[:, 1] - g.oy1 - g.oy2 + g.h2) / g.spacing
+    assert np.abs(cx - np.round(cx)).max() < 1e-4 and np.abs(cy - np.round(cy)).max() < 1e-4
+    cx, cy = np.round(cx).astype(int), np.round(cy).astype(int)
+    assert cx.min() >= 0 and cx.max() < g.nx and cy.min() >= 0 and cy.max() < g.ny
+    cell = cx * g.ny + cy
+    assert all(len(set(row)) == env.N for row in cell)          # distinct cells (replace=False)
+    # every cell is used, roughly uniformly
+    counts = np.bincount(cell.ravel(), minlength=g.nx * g.ny)
+    expect = E * env.N / (g.nx * g.ny)
+    assert counts.min() > 0.8 * expect and counts.max() < 1.2 * expect
+    if scenario == "Warehouse":
+        th = P[:, 2]
+        assert th.min() >= -np.pi - 1e-6 and th.max() < np.pi + 1e-6 and abs(th.mean()) < 0.05
+    else:
+        assert np.abs(P[:, 2]).max() == 0.0
+    if scenario == "PredatorCapturePrey":
+        q = env.params.prey_grid
+        L = env.prey_loc.double().cpu().numpy()
+        px = np.round((L[:, :, 0] - q.ox1 + q.w2) / q.spacing).astype(int)
+        py = np.round((L[:, :, 1] + q.h2) / q.spacing).astype(int)
+        pc = px * q.ny + py
+        assert all(len(set(row)) == env.P for row in pc)
+        assert L[:, :, 0].min() >= 0.5 - 1e-5                   # prey spawn right of PREY_INIT_LEFT_THRESH
+    if scenario == "MaterialTransport":
+        z = env.zone_load.double().cpu().numpy()
+        assert abs(z[:, 0].mean() - 99.5) < 1.0 and abs(z[:, 0].std() - 10) < 1.0   # int() truncates: mean -0.5
+        assert abs(z[:, 1].mean() - 19.5) < 0.5 and abs(z[:, 1].std() - 4) < 0.5
+    env.close()

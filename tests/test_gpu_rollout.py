@@ -1,0 +1,147 @@
+"""Free-running rollouts on the GPU (auto-reset on) against the float32 oracle stepping the same
+envs on the CPU with the oracle's reset twin: every output of every step, bit for bit, over whole
+episodes including violations, captures, loading/unloading and resets.  Plus size-independent
+properties at the bench size (4096 envs)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_reset_params
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 260),
+         ("PredatorCapturePrey", {"num_neighbors": 2, "capability_aware": True}, 5, 120),
+         ("Warehouse", {"n_agents": 8}, 5, 230),
+         ("Warehouse", {}, 5, 120),
+         ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}, 20, 160),
+         ("MaterialTransport", {}, 20, 100),
+         ("PredatorCapturePrey", {"predator": 6, "capture": 6, "n_agents": 12, "num_prey": 10, "start_dist": 0.25,
+                                  "num_neighbors": 4}, 5, 60)]
+
+
+def _oracle_reset(oracle_lib, orc, rp, seed, e, episode):
+    p, q, z = oracle_lib.reset_env_f32(rp, seed, e, episode)
+    orc.poses[e] = p
+    orc.carry[e] = 0
+    orc.steps[e] = 0
+    orc.prey_loc[e] = q[:orc.prey_loc.shape[1]]
+    orc.prey_sensed[e] = 0
+    orc.prey_captured[e] = 0
+    orc.loaded[e] = 0
+    orc.load[e] = 0
+    if orc.scenario == "MaterialTransport":
+        orc.zone_load[e] = z
+        orc.messages[e] = 0
+
+
+@pytest.mark.parametrize("scenario,ov,n_act,steps", CASES)
+def test_rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib):
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    E, seed = 192, 99
+    env = VecRobotariumEnv(scenario, E, overrides=ov, seed=seed, auto_reset=True, collect_qp_stats=True)
+    cfg = dict(env.cfg)
+    orc = oracle_lib.OracleVecEnv(scenario, cfg, E, dtype=np.float32)
+    rp = oracle_reset_params(oracle_lib, env.params)
+    env.reset()
+    episodes = np.zeros(E, np.int64)
+    for e in range(E):
+        _oracle_reset(oracle_lib, orc, rp, seed, e, 0)
+    rng = np.random.RandomState(5)
+    n_done = n_viol = 0
+    ret = np.zeros(E, np.float32)
+    ret_sum = np.zeros(E, np.float32)
+    for t in range(steps):
+        a = rng.randint(0, n_act, size=(E, env.N)).astype(np.int32)
+        obs, rew, done, info = env.step(torch.as_tensor(a, device=env.device))
+        o_obs, o_rew, o_done, o_info = orc.step(a)
+        g = {"obs": obs.cpu().numpy(), "reward": rew.cpu().numpy(), "done": done.cpu().numpy().astype(np.uint8),
+             "dist": info["dist_travelled"].cpu().numpy(), "viol": info["violation"].cpu().numpy(),
+             "remaining": info["remaining"].cpu().numpy()}
+        assert np.array_equal(g["done"], o_done), t
+        assert np.array_equal(g["viol"], o_info["violation"]), t
+        assert np.array_equal(g["remaining"], o_info["remaining"]), t
+        assert np.array_equal(g["obs"].view(np.uint32), o_obs.view(np.uint32)), t
+        assert np.array_equal(g["reward"].view(np.uint32), o_rew.view(np.uint32)), t
+        assert np.array_equal(g["dist"].view(np.uint32), o_info["dist_travelled"].view(np.uint32)), t
+        assert np.array_equal(env.qp_sweeps.cpu().numpy(), orc.qp_sweeps), t
+        # rollout statistics (misc.py:178-185)
+        r = o_rew[:, 0] if env.params.shared_reward else o_rew.sum(axis=1, dtype=np.float32) if False else None
+        if env.params.shared_reward:
+            ret = ret + o_rew[:, 0]
+        else:
+            s = np.zeros(E, np.float32)
+            for k in range(env.N):
+                s = s + o_rew[:, k]
+            ret = ret + s
+        for e in np.nonzero(o_done)[0]:
+            ret_sum[e] = ret_sum[e] + ret[e]
+            ret[e] = 0
+            episodes[e] += 1
+            _oracle_reset(oracle_lib, orc, rp, seed, e, int(episodes[e]))
+        n_done += int(o_done.sum())
+        n_viol += int((o_info["violation"] > 0).sum())
+        # state after the (possibly reset) step
+        assert np.array_equal(env.poses.cpu().numpy().view(np.uint32), orc.poses.view(np.uint32)), t
+        assert np.array_equal(env.episode_steps.cpu().numpy(), orc.steps), t
+    assert n_done > 0
+    assert np.array_equal(env.done_count.cpu().numpy(), episodes)
+    assert np.array_equal(env.done_return_sum.cpu().numpy().view(np.uint32), ret_sum.view(np.uint32))
+    assert np.array_equal(env.ep_return.cpu().numpy().view(np.uint32), ret.view(np.uint32))
+    env.close()
+
+
+def test_bench_size_properties():
+    """4096 x 5 (BASELINE configs[1]): properties that need no oracle."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    E = 4096
+    env = VecRobotariumEnv("PredatorCapturePrey", E, overrides={"predator": 3, "capture": 2, "n_agents": 5}, seed=3)
+    env.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(0)
+    total_done = 0
+    for t in range(120):
+        a = torch.randint(0, 5, (E, 5), generator=g, device=env.device, dtype=torch.int32)
+        prev = env.poses.clone()
+        steps_before = env.episode_steps.clone()
+        obs, rew, done, info = env.step(a)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        # a robot moves at most 29 * 0.033 * 0.2 m per step; dist_travelled obeys the same bound
+        live = ~done
+        d = (env.poses[live][:, :2] - prev[live][:, :2]).norm(dim=1)
+        assert float(d.max()) <= 29 * 0.033 * 0.2 + 1e-5
+        assert float(info["dist_travelled"].max()) <= 29 * 0.033 * 0.2 + 0.0067 + 1e-5
+        assert float(env.poses[:, 2].abs().max()) <= np.pi + 1e-6
+        # shared reward: identical across agents; violation <=> reward -5 and done
+        assert torch.equal(rew, rew[:, :1].expand_as(rew))
+        v = info["violation"] > 0
+        assert bool((rew[v, 0] == -5).all()) and bool(done[v].all())
+        # own block of the observation is the agent's position (of the terminal state for done envs)
+        assert torch.equal(obs[live][:, :, 0], env.poses[live][:, 0]) and torch.equal(obs[live][:, :, 1], env.poses[live][:, 1])
+        # step counters: +1, or 0 after an auto-reset
+        assert torch.equal(env.episode_steps[live], steps_before[live] + 1)
+        assert int(env.episode_steps[done].abs().sum()) == 0
+        total_done += int(done.sum())
+    assert total_done > 0
+    assert int(env.done_count.sum()) == total_done
+    env.close()
+
+
+def test_step_is_deterministic_and_shard_invariant():
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    ov = {"n_agents": 8}
+    a = torch.randint(0, 5, (60, 512, 8), device="cuda:0", dtype=torch.int32)
+    full = VecRobotariumEnv("Warehouse", 512, overrides=ov, seed=11)
+    lo = VecRobotariumEnv("Warehouse", 256, overrides=ov, seed=11, env_offset=0)
+    hi = VecRobotariumEnv("Warehouse", 256, overrides=ov, seed=11, env_offset=256)
+    for env in (full, lo, hi):
+        env.reset()
+    for t in range(60):
+        o, r, d, _ = full.step(a[t])
+        o1, r1, d1, _ = lo.step(a[t, :256].contiguous())
+        o2, r2, d2, _ = hi.step(a[t, 256:].contiguous())
+        assert torch.equal(o, torch.cat([o1, o2])) and torch.equal(r, torch.cat([r1, r2])) and \
+            torch.equal(d, torch.cat([d1, d2]))
+    assert torch.equal(full.done_return_sum, torch.cat([lo.done_return_sum, hi.done_return_sum]))
