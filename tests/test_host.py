@@ -1,0 +1,177 @@
+"""Host logic without a GPU: the C-ABI library loads and exports every symbol include/robogym.h
+declares, config -> parameter block, sharding, loud failure when no HIP device exists, and the
+N > 1 collectives on gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "robogym.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rg_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from marbler_amd import _lib
+    lib = _lib.load()
+    names = _declared_functions()
+    assert {"rg_create", "rg_destroy", "rg_bind_state", "rg_reset", "rg_step", "rg_get_obs", "rg_abi_version",
+            "rg_last_error"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_lib.EXPORTS)
+    assert lib.rg_abi_version() == _lib.ABI_VERSION
+    assert lib.rg_sizeof_params() == ctypes.sizeof(_lib.RgScenarioParams)
+    assert lib.rg_sizeof_state() == ctypes.sizeof(_lib.RgState)
+    assert lib.rg_sizeof_step_io() == ctypes.sizeof(_lib.RgStepIO)
+
+
+def test_create_rejects_bad_parameters_without_touching_a_gpu():
+    from marbler_amd import _lib, load_config, make_params
+    lib = _lib.load()
+    p = make_params("PredatorCapturePrey", load_config("PredatorCapturePrey"))
+    p.n_agents = 99
+    assert not lib.rg_create(ctypes.byref(p), 4, 0, 0, None)
+    assert b"n_agents" in lib.rg_last_error()
+    assert lib.rg_destroy(None) != 0 and lib.rg_step(None, None, None, 0, 0) != 0
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from marbler_amd import RobogymError, VecRobotariumEnv, Wrapper
+    with pytest.raises(RobogymError):
+        VecRobotariumEnv("PredatorCapturePrey", 4)
+    with pytest.raises(RobogymError):
+        VecRobotariumEnv("PredatorCapturePrey", 4, device="cpu")
+    with pytest.raises(RobogymError):
+        Wrapper("Warehouse")
+    # rg_create itself refuses when no HIP device exists
+    from marbler_amd import _lib, load_config, make_params
+    lib = _lib.load()
+    p = make_params("Warehouse", load_config("Warehouse"))
+    assert not lib.rg_create(ctypes.byref(p), 4, 0, 0, None)
+    assert b"no CPU fallback" in lib.rg_last_error()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "marbler_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/_build" not in src and "liboracle" not in src, f
+
+
+def test_params_follow_the_reference_configs():
+    from marbler_amd import load_config, make_params
+    p = make_params("PredatorCapturePrey", load_config("PredatorCapturePrey"))
+    assert (p.n_agents, p.obs_dim, p.num_prey, p.num_neighbors, p.update_frequency, p.max_episode_steps) == \
+        (4, 16, 6, 3, 29, 80)
+    assert (p.agent_grid.nx, p.agent_grid.ny, p.prey_grid.nx, p.prey_grid.ny) == (3, 6, 4, 9)
+    assert list(p.sensing_radius)[:4] == pytest.approx([0.45, 0.45, 0, 0]) and \
+        list(p.capture_radius)[:4] == pytest.approx([0, 0, 0.25, 0.25])
+    assert p.barrier_has_unsafe_gain == 1 and p.safety_radius == pytest.approx(0.2)
+    assert p.shared_reward == 1 and p.keep_theta == 0
+    p = make_params("PredatorCapturePrey", load_config("PredatorCapturePrey", overrides={
+        "predator": 3, "capture": 2, "capability_aware": True, "barrier_certificate": "default"}))
+    assert (p.n_agents, p.obs_dim, p.barrier_has_unsafe_gain) == (5, 24, 0) and p.safety_radius == pytest.approx(0.17)
+    w = make_params("Warehouse", load_config("Warehouse", overrides={"n_agents": 8}))
+    assert (w.n_agents, w.obs_dim, w.agent_grid.nx, w.agent_grid.ny, w.keep_theta, w.shared_reward) == (8, 18, 4, 3, 1, 0)
+    assert abs(w.agent_grid.ox1 + w.agent_grid.ox2) < 1e-7        # the four shifts of warehouse.py:95-98 cancel
+    m = make_params("MaterialTransport", load_config("MaterialTransport"))
+    assert (m.n_agents, m.obs_dim, m.update_frequency, m.agent_grid.nx, m.agent_grid.ny) == (4, 9, 74, 1, 6)
+    assert list(m.torque)[:4] == [5, 5, 15, 15] and list(m.agent_step)[:4] == pytest.approx([.45, .45, .15, .15])
+    with pytest.raises(ValueError, match="grid cells"):           # 6 agents on the default 1x6 grid (Appendix C)
+        make_params("MaterialTransport", load_config("MaterialTransport", overrides={
+            "n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3}))
+    with pytest.raises(ValueError):
+        make_params("Warehouse", load_config("Warehouse", overrides={"robotarium": True}))
+    with pytest.raises(KeyError):
+        make_params("ArcticTransport", {})
+
+
+def test_params_roundtrip_and_sharding():
+    from marbler_amd import load_config, make_params
+    from marbler_amd.dist import shard
+    from marbler_amd.params import params_from_bytes, params_to_bytes
+    p = make_params("Warehouse", load_config("Warehouse"))
+    b = params_to_bytes(p)
+    assert len(b) < 1024
+    assert params_to_bytes(params_from_bytes(b)) == b
+    for total, world in ((32768, 8), (4096, 1), (10, 3), (7, 8)):
+        spans = [shard(total, r, world) for r in range(world)]
+        assert sum(c for _, c in spans) == total
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def test_spaces_match_the_reference_constructors():
+    from marbler_amd import load_config, make_params
+    from marbler_amd.spaces import scenario_spaces
+    for name, nact, lo, hi in (("PredatorCapturePrey", 5, -5, 3), ("Warehouse", 5, -1.5, 1.5),
+                               ("MaterialTransport", 20, -1.5, 1.5)):
+        p = make_params(name, load_config(name))
+        a, o = scenario_spaces(name, p)
+        assert len(a) == len(o) == p.n_agents
+        assert a[0].n == nact and tuple(o[0].shape) == (p.obs_dim,)
+        assert float(np.min(o[0].low)) == lo and float(np.max(o[0].high)) == hi
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import torch
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from marbler_amd import dist as rgdist
+    from marbler_amd import load_config, make_params
+    from marbler_amd.params import params_to_bytes
+    r, w, _ = rgdist.init_from_env(backend="gloo")
+    src_cfg = {"n_agents": 8, "goal_width": 0.4} if r == 0 else {}
+    p = make_params("Warehouse", load_config("Warehouse", overrides=src_cfg))
+    p = rgdist.broadcast_params(p, src=0, device="cpu")
+    off, cnt = rgdist.shard(9, r, w)                               # 9 envs over 2 ranks: 5 + 4
+    rs = torch.arange(off, off + cnt, dtype=torch.float32) * 0.5
+    cs = torch.arange(off, off + cnt, dtype=torch.int32)
+    ss = cs * 10
+    out = rgdist.gather_episode_stats(rs, cs, ss, dst=0)
+    q.put((r, params_to_bytes(p), None if out is None else [t.tolist() for t in out]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    from marbler_amd import load_config, make_params
+    from marbler_amd.params import params_to_bytes
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = params_to_bytes(make_params("Warehouse", load_config("Warehouse", overrides={"n_agents": 8, "goal_width": 0.4})))
+    assert res[0][1] == want and res[1][1] == want                 # rank 1 received rank 0's block
+    assert res[1][2] is None
+    rs, cs, ss = res[0][2]
+    assert rs == [0.5 * i for i in range(9)] and cs == list(range(9)) and ss == [10 * i for i in range(9)]
