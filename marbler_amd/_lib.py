@@ -11,7 +11,7 @@ MAX_AGENTS, MAX_PREY = 16, 64
 ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librobogym_hip.so")
+LIB_PATH = os.environ.get("ROBOGYM_LIB") or os.path.join(_HERE, "librobogym_hip.so")  # override: diagnostic builds
 
 
 class RgGrid(C.Structure):

@@ -35,16 +35,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines / out: diagnostic variants (e.g. defines=("RG_STAMPS",), out=".../librobogym_stamps.so")."""
+    if out is None and not force and not needs_build():
         return LIB
+    out = out or LIB
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-shared", "-std=c++17",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-o", LIB] + \
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + [f"-D{d}" for d in defines] + ["-o", out] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -161,6 +161,7 @@ int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t 
     if (!actions || !io) return fail(-23, "actions or io is NULL");
     if (!io->obs || !io->reward || !io->done || !io->dist_travelled || !io->violation || !io->remaining)
         return fail(-24, "every rg_step_io array except qp_sweeps is required");
+    if (reinterpret_cast<uintptr_t>(io->obs) & 15u) return fail(-26, "obs must be 16-byte aligned");
     a.actions = actions;
     a.io = *io;
     a.auto_reset = auto_reset;
@@ -172,6 +173,7 @@ int rg_get_obs(rg_handle *h, float *obs) {
     rg::KernelArgs a;
     if (int rc = fill_args(h, a)) return rc;
     if (!obs) return fail(-23, "obs is NULL");
+    if (reinterpret_cast<uintptr_t>(obs) & 15u) return fail(-26, "obs must be 16-byte aligned");
     a.io.obs = obs;
     return launched(rg::launch_step(a, true, h->stream));
 }

@@ -2,21 +2,24 @@
 //
 // One launch = one env step for E envs: goal generation, U sim sub-iterations (controller with
 // the barrier-certificate QP every 15th, collision/boundary validation, Euler integration),
-// then the scenario's tracking / observation / reward / termination -- all with the env's
-// state in registers.  HBM traffic is the algorithmic I/O only.
+// then the scenario's tracking / observation / reward / termination, and the reset of envs that
+// finished -- all with the env's state in registers.  HBM traffic is the algorithmic I/O only
+// (measured with rocprofv3 FETCH_SIZE / WRITE_SIZE in profiles/).
 //
 // Mapping: a lane GROUP of GW lanes (GW = 4, 8 or 16 >= N) owns one env, one lane per agent; a
 // 64-lane wavefront carries 64/GW envs; one wavefront per workgroup (no cross-wave sync
-// anywhere).  The O(N^2) pair work (collision scan, QP constraint sweeps, neighbour
-// distances) runs as GW-1 "rounds": in round k lane a is paired with lane a^k, which is a
-// 1-factorisation of the complete graph on the group -- disjoint pairs, so a Gauss-Seidel
-// sweep over the QP constraints in this order is pair-parallel yet identical to the
-// sequential sweep of the CPU oracle.  Partner data moves by DPP (row-local lane permutes on
-// the VALU), never through memory.  Per-env flags reduce with one wave ballot.
+// anywhere).  The O(N^2) pair work (collision scan, QP constraint sweeps) runs as GW-1
+// "rounds": in round k lane a is paired with lane a^k, a 1-factorisation of the complete graph
+// on the group -- disjoint pairs, so a Gauss-Seidel sweep over the QP constraints in this
+// order is pair-parallel yet identical to the sequential sweep of the CPU oracle.  Partner
+// data moves by DPP (row-local lane permutes on the VALU), never through memory; per-env
+// reductions are DPP butterflies or one wave ballot; the per-env prey block and the agents'
+// own-observation rows are staged in LDS.
 //
-// No MFMA: there is no dense contraction on this path.  The kernel is a latency-bound
-// dependent chain (U x {sincos, 7 pair rounds, sqrt}), so the design goal is the shortest
-// per-lane instruction chain, not bytes.
+// No MFMA: there is no dense contraction on this path.  At the benchmark size (4096 envs =
+// 512 wavefronts on 1024 SIMDs) the kernel is a latency-bound dependent chain per wavefront, so
+// the design goal is the shortest per-lane instruction chain with independent work interleaved
+// (sub-steps are processed in chunks of 4 for ILP), not bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,38 +31,40 @@
 
 namespace rg {
 
+constexpr int WAVE = 64;
+constexpr int CHUNK = 4;        // sub-steps validated together (ILP across independent test chains)
+constexpr int MAX_DRAWS = 128;  // u32 draws per reset: 4 + 2N + P <= 4 + 32 + 64, rounded up to blocks
+
 // ------------------------------------------------------------------ lane exchange (DPP)
 template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float,
-                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 // value held by lane (lane ^ K), K in 1..15, within a 16-lane row
 template <int K>
-__device__ __forceinline__ float xor_lane(float v) {
-    static_assert(K >= 1 && K <= 15, "xor distance");
-    constexpr int QP1 = 0xB1, QP2 = 0x4E, QP3 = 0x1B;           // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
-    constexpr int HALF_MIRROR = 0x141, MIRROR = 0x140, ROR8 = 0x128;
-    if constexpr (K == 1) return dpp_f<QP1>(v);
-    else if constexpr (K == 2) return dpp_f<QP2>(v);
-    else if constexpr (K == 3) return dpp_f<QP3>(v);
-    else if constexpr (K == 7) return dpp_f<HALF_MIRROR>(v);
-    else if constexpr (K == 4) return dpp_f<QP3>(dpp_f<HALF_MIRROR>(v));
-    else if constexpr (K == 5) return dpp_f<QP2>(dpp_f<HALF_MIRROR>(v));
-    else if constexpr (K == 6) return dpp_f<QP1>(dpp_f<HALF_MIRROR>(v));
-    else if constexpr (K == 15) return dpp_f<MIRROR>(v);
-    else if constexpr (K == 8) return dpp_f<ROR8>(v);
-    else if constexpr (K == 9) return dpp_f<QP1>(dpp_f<ROR8>(v));
-    else if constexpr (K == 10) return dpp_f<QP2>(dpp_f<ROR8>(v));
-    else if constexpr (K == 11) return dpp_f<QP3>(dpp_f<ROR8>(v));
-    else if constexpr (K == 12) return dpp_f<QP3>(dpp_f<MIRROR>(v));
-    else if constexpr (K == 13) return dpp_f<QP2>(dpp_f<MIRROR>(v));
-    else return dpp_f<QP1>(dpp_f<MIRROR>(v));
-}
-
-template <int K>
 __device__ __forceinline__ int xor_lane_i(int v) {
-    return __builtin_bit_cast(int, xor_lane<K>(__builtin_bit_cast(float, v)));
+    static_assert(K >= 1 && K <= 15, "xor distance");
+    constexpr int QP1 = 0xB1, QP2 = 0x4E, QP3 = 0x1B;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
+    constexpr int HALF_MIRROR = 0x141, MIRROR = 0x140, ROR8 = 0x128;
+    if constexpr (K == 1) return dpp_i<QP1>(v);
+    else if constexpr (K == 2) return dpp_i<QP2>(v);
+    else if constexpr (K == 3) return dpp_i<QP3>(v);
+    else if constexpr (K == 7) return dpp_i<HALF_MIRROR>(v);
+    else if constexpr (K == 4) return dpp_i<QP3>(dpp_i<HALF_MIRROR>(v));
+    else if constexpr (K == 5) return dpp_i<QP2>(dpp_i<HALF_MIRROR>(v));
+    else if constexpr (K == 6) return dpp_i<QP1>(dpp_i<HALF_MIRROR>(v));
+    else if constexpr (K == 15) return dpp_i<MIRROR>(v);
+    else if constexpr (K == 8) return dpp_i<ROR8>(v);
+    else if constexpr (K == 9) return dpp_i<QP1>(dpp_i<ROR8>(v));
+    else if constexpr (K == 10) return dpp_i<QP2>(dpp_i<ROR8>(v));
+    else if constexpr (K == 11) return dpp_i<QP3>(dpp_i<ROR8>(v));
+    else if constexpr (K == 12) return dpp_i<QP3>(dpp_i<MIRROR>(v));
+    else if constexpr (K == 13) return dpp_i<QP2>(dpp_i<MIRROR>(v));
+    else return dpp_i<QP1>(dpp_i<MIRROR>(v));
+}
+template <int K>
+__device__ __forceinline__ float xor_lane(float v) {
+    return __builtin_bit_cast(float, xor_lane_i<K>(__builtin_bit_cast(int, v)));
 }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -72,24 +77,31 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// max over the lanes of a group (butterfly; every stage is a single DPP permute)
+// reductions over the lanes of a group: butterflies whose every stage is ONE DPP permute
+// (xor 1, xor 2, then the half-row / row mirrors)
 template <int GW>
 __device__ __forceinline__ float group_max(float v) {
     v = fmaxf(v, xor_lane<1>(v));
     v = fmaxf(v, xor_lane<2>(v));
-    if constexpr (GW >= 8) v = fmaxf(v, xor_lane<7>(v));    // quads {0-3} <-> {4-7}: one row_half_mirror
-    if constexpr (GW >= 16) v = fmaxf(v, xor_lane<15>(v));  // halves of the row: one row_mirror
+    if constexpr (GW >= 8) v = fmaxf(v, xor_lane<7>(v));
+    if constexpr (GW >= 16) v = fmaxf(v, xor_lane<15>(v));
     return v;
 }
-
-// does any lane of my group have `pred` set?  (one v_cmp -> SGPR pair ballot, then bit tests)
+template <int GW>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
+    v |= static_cast<uint32_t>(xor_lane_i<1>(static_cast<int>(v)));
+    v |= static_cast<uint32_t>(xor_lane_i<2>(static_cast<int>(v)));
+    if constexpr (GW >= 8) v |= static_cast<uint32_t>(xor_lane_i<7>(static_cast<int>(v)));
+    if constexpr (GW >= 16) v |= static_cast<uint32_t>(xor_lane_i<15>(static_cast<int>(v)));
+    return v;
+}
+// does any lane of my group have `pred` set?  (rare paths only: one ballot, then bit tests)
 template <int GW>
 __device__ __forceinline__ bool group_any(bool pred, int gbase) {
     const unsigned long long m = __ballot(pred);
     constexpr unsigned long long GM = (GW == 64) ? ~0ull : ((1ull << GW) - 1ull);
     return ((m >> gbase) & GM) != 0ull;
 }
-
 
 struct Consts {  // derived scalars, computed in binary32 in the same form as the oracle
     float dt, pd, inv_pd, r2, wlim, vmax, wmax, pvl, bml;
@@ -204,137 +216,148 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     return my_sweeps;
 }
 
+// ------------------------------------------------------------------ LDS scratch (one wavefront)
+template <int GW>
+struct alignas(16) Lds {
+    float prey[WAVE / GW][RG_MAX_PREY * 2];  // the env's prey block (PredatorCapturePrey)
+    float own[WAVE][8];                      // each agent's own-observation row (<= 6 floats)
+    float ax[WAVE], ay[WAVE];                // MaterialTransport sequential replay / reward sum
+    int aload[WAVE];
+    uint32_t draws[WAVE / GW][MAX_DRAWS];    // reset: Philox output
+    uint8_t perm[WAVE / GW][64];             // reset: Fisher-Yates permutation of the grid cells
+    uint8_t sel[WAVE / GW][64];              // reset: chosen cells
+};
+
 // ------------------------------------------------------------------ reset sampler (a17)
 // misc.py:49-63 -> rps generate_initial_conditions (Appendix A.7): N distinct cells of an
 // nx x ny grid, then the scenario's shift.  The reference draws from NumPy's global MT19937;
-// here every (global env, episode) pair owns a Philox4x32-10 stream (DESIGN.md "reset").
-using GridSpec = rg_grid;
-
-struct Draws {
-    uint32_t k0, k1, c0, c1, c2;
-    uint32_t blk[4];
-    uint32_t cur;   // index of the cached block, 0xFFFFFFFF = none
-    uint32_t next;  // next draw index
-    __device__ __forceinline__ uint32_t u32() {
-        const uint32_t b = next >> 2;
-        if (b != cur) {
-            philox4x32_10(c0, c1, c2, b, k0, k1, blk);
-            cur = b;
-        }
-        const uint32_t lane = next & 3u;
-        ++next;
-        return lane == 0 ? blk[0] : lane == 1 ? blk[1] : lane == 2 ? blk[2] : blk[3];
-    }
-};
-
-// One lane (the group's lane 0) runs the sequential sampler for its env, using `perm` (LDS
-// scratch, >= nx*ny bytes) for the partial Fisher-Yates shuffle.
-__device__ inline void sample_cells(Draws &d, const GridSpec &g, int count, uint8_t *perm, float *outx, float *outy,
-                                    int stride) {
-    const int C = g.nx * g.ny;
-    for (int i = 0; i < C; ++i) perm[i] = static_cast<uint8_t>(i);
-    for (int i = 0; i < count; ++i) {
-        const uint32_t r = d.u32();
-        const int j = i + static_cast<int>((static_cast<uint64_t>(r) * static_cast<uint32_t>(C - i)) >> 32);
-        const uint8_t t = perm[i];
-        perm[i] = perm[j];
-        perm[j] = t;
-        const int cell = perm[i];
-        const int cx = cell / g.ny, cy = cell - cx * g.ny;
-        const float x = static_cast<float>(cx) * g.spacing - g.w2;
-        const float y = static_cast<float>(cy) * g.spacing - g.h2;
-        outx[i * stride] = (x + g.ox1) + g.ox2;
-        outy[i * stride] = (y + g.oy1) + g.oy2;
-    }
-}
-
+// here every (global env, episode) pair owns a Philox4x32-10 stream (DESIGN.md "reset").  Draw
+// order: [MaterialTransport: 4 for the two zone loads] N cells, N headings, [PCP: P prey cells].
+// The whole wave calls this (wave-uniform); groups with do_reset set take part: Philox blocks
+// and the permutation fill are spread over the group's lanes, the short Fisher-Yates chain runs
+// on the group's lane 0, and every lane writes its own agent's state.
 __device__ __forceinline__ float uniform01(uint32_t r) { return static_cast<float>(r >> 8) * 5.9604644775390625e-08f; }
 
-// int(np.random.normal(mean, std)) by Box-Muller on the spec'd log / sincos
-__device__ inline int normal_int(Draws &d, float mean, float stdv) {
-    const uint32_t r1 = d.u32(), r2 = d.u32();
+__device__ __forceinline__ int normal_int(uint32_t r1, uint32_t r2, float mean, float stdv) {
+    // int(np.random.normal(mean, std)) by Box-Muller on the spec'd log / sincos
     const float u1 = static_cast<float>((r1 >> 8) + 1u) * 5.9604644775390625e-08f;  // (0, 1]
     const float u2 = uniform01(r2);
     const float rad = __builtin_sqrtf(-2.0f * log_spec(u1));
     float sn, cs;
     sincos_spec(u2 * 6.283185482025146484375f - 3.1415927410125732421875f, sn, cs);
-    const float z = rad * cs;
-    return static_cast<int>(mean + stdv * z);
+    return static_cast<int>(mean + stdv * (rad * cs));
 }
 
-
-// Resets env e (called by ONE lane per env).  Writes the state arrays in HBM.
-template <int SCN>
-__device__ inline void reset_env(const KernelArgs &a, int e, uint8_t *perm) {
-    const rg_scenario_params &p = a.p;
-    const int N = p.n_agents;
-    const int32_t episode = a.st.reset_count[e];
-    a.st.reset_count[e] = episode + 1;
-    const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
-    Draws d;
-    d.k0 = static_cast<uint32_t>(a.seed);
-    d.k1 = static_cast<uint32_t>(a.seed >> 32);
-    d.c0 = static_cast<uint32_t>(ge);
-    d.c1 = static_cast<uint32_t>(ge >> 32);
-    d.c2 = static_cast<uint32_t>(episode);
-    d.cur = 0xFFFFFFFFu;
-    d.next = 0;
-    float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
-    if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {  // MaterialTransport.py:99-100 come first
-        a.st.zone_load[2 * e + 0] = normal_int(d, p.zone1_mean, p.zone1_std);
-        a.st.zone_load[2 * e + 1] = normal_int(d, p.zone2_mean, p.zone2_std);
-        for (int i = 0; i < 4; ++i) a.st.messages[4 * e + i] = 0;
-    }
-    sample_cells(d, p.agent_grid, N, perm, X, X + N, 1);
-    for (int i = 0; i < N; ++i) {
-        const float th = uniform01(d.u32()) * 6.283185482025146484375f - 3.1415927410125732421875f;
-        X[2 * N + i] = p.keep_theta ? th : 0.0f;
-        a.st.carry_dist[static_cast<size_t>(e) * N + i] = 0.0f;
-        if constexpr (SCN == RG_SCN_WAREHOUSE) a.st.loaded[static_cast<size_t>(e) * N + i] = 0;
-        if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) a.st.load[static_cast<size_t>(e) * N + i] = 0;
-    }
-    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-        const int P = p.num_prey;
-        float *pl = a.st.prey_loc + static_cast<size_t>(e) * P * 2;
-        sample_cells(d, p.prey_grid, P, perm, pl, pl + 1, 2);
-        for (int i = 0; i < P; ++i) {
-            a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
-            a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
+template <int GW>
+__device__ __forceinline__ void fisher_yates(Lds<GW> &lds, int g, int ag, bool do_reset, const rg_grid &grid,
+                                             int count, int first_draw) {
+    const int C = grid.nx * grid.ny;
+    if (do_reset)
+        for (int i = ag; i < C; i += GW) lds.perm[g][i] = static_cast<uint8_t>(i);
+    __syncthreads();
+    if (do_reset && ag == 0) {
+        for (int i = 0; i < count; ++i) {
+            const uint32_t r = lds.draws[g][first_draw + i];
+            const int j = i + static_cast<int>((static_cast<uint64_t>(r) * static_cast<uint32_t>(C - i)) >> 32);
+            const uint8_t t = lds.perm[g][i];
+            const uint8_t pj = lds.perm[g][j];
+            lds.perm[g][j] = t;
+            lds.perm[g][i] = pj;
+            lds.sel[g][i] = pj;
         }
     }
-    a.st.episode_steps[e] = 0;
+    __syncthreads();
 }
 
-// ------------------------------------------------------------------ scenario epilogues
-constexpr int WAVE = 64;
+__device__ __forceinline__ void cell_xy(const rg_grid &grid, int cell, float &x, float &y) {
+    const int cx = cell / grid.ny, cy = cell - cx * grid.ny;
+    const float fx = static_cast<float>(cx) * grid.spacing - grid.w2;
+    const float fy = static_cast<float>(cy) * grid.spacing - grid.h2;
+    x = (fx + grid.ox1) + grid.ox2;
+    y = (fy + grid.oy1) + grid.oy2;
+}
 
-struct Lds {  // per-workgroup (= per-wave) scratch
-    float prey[WAVE / 4][RG_MAX_PREY * 2];
-    uint8_t sensed[WAVE / 4][RG_MAX_PREY];
-    uint8_t captured[WAVE / 4][RG_MAX_PREY];
-    float ax[WAVE], ay[WAVE];
-    int aload[WAVE];
-    uint8_t perm[WAVE / 4][64];
-};
+template <int SCN, int GW>
+__device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, int e, int g, int ag, bool do_reset) {
+    const rg_scenario_params &p = a.p;
+    const int N = p.n_agents;
+    const int P = (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) ? p.num_prey : 0;
+    constexpr int ZD = (SCN == RG_SCN_MATERIAL_TRANSPORT) ? 4 : 0;
+    const int ndraws = ZD + 2 * N + P;
+    int32_t episode = 0;
+    if (do_reset) {
+        episode = a.st.reset_count[e];
+        const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
+        for (int b = ag; 4 * b < ndraws; b += GW) {
+            uint32_t blk[4];
+            philox4x32_10(static_cast<uint32_t>(ge), static_cast<uint32_t>(ge >> 32), static_cast<uint32_t>(episode),
+                          static_cast<uint32_t>(b), static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32),
+                          blk);
+            lds.draws[g][4 * b + 0] = blk[0];
+            lds.draws[g][4 * b + 1] = blk[1];
+            lds.draws[g][4 * b + 2] = blk[2];
+            lds.draws[g][4 * b + 3] = blk[3];
+        }
+    }
+    fisher_yates<GW>(lds, g, ag, do_reset, p.agent_grid, N, ZD);  // syncs inside: draws + perm visible
+    if (do_reset && ag < N) {
+        float x, y;
+        cell_xy(p.agent_grid, lds.sel[g][ag], x, y);
+        const float th = uniform01(lds.draws[g][ZD + N + ag]) * 6.283185482025146484375f - 3.1415927410125732421875f;
+        float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
+        X[ag] = x;
+        X[N + ag] = y;
+        X[2 * N + ag] = p.keep_theta ? th : 0.0f;
+        a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
+        if constexpr (SCN == RG_SCN_WAREHOUSE) a.st.loaded[static_cast<size_t>(e) * N + ag] = 0;
+        if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
+            a.st.load[static_cast<size_t>(e) * N + ag] = 0;
+            if (ag < 4) a.st.messages[4 * e + ag] = 0;
+        }
+    }
+    if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {  // MaterialTransport.py:99-100
+        if (do_reset && ag < 2) {
+            const float mean = ag == 0 ? p.zone1_mean : p.zone2_mean, sd = ag == 0 ? p.zone1_std : p.zone2_std;
+            a.st.zone_load[2 * e + ag] = normal_int(lds.draws[g][2 * ag], lds.draws[g][2 * ag + 1], mean, sd);
+        }
+    }
+    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
+        fisher_yates<GW>(lds, g, ag, do_reset, p.prey_grid, P, ZD + 2 * N);
+        if (do_reset) {
+            for (int i = ag; i < P; i += GW) {
+                float x, y;
+                cell_xy(p.prey_grid, lds.sel[g][i], x, y);
+                float *pl = a.st.prey_loc + (static_cast<size_t>(e) * P + i) * 2;
+                pl[0] = x;
+                pl[1] = y;
+                a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
+                a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
+            }
+        }
+    }
+    if (do_reset && ag == 0) {
+        a.st.reset_count[e] = episode + 1;
+        a.st.episode_steps[e] = 0;
+    }
+}
 
-// K nearest neighbours' own-observations into obs slots 1..K (ascending distance, ties ->
-// lower index: the canonical order for misc.py:20-25); K >= N-1: all others in index order.
+// ------------------------------------------------------------------ neighbour observations
+// K nearest neighbours' own-observation rows (staged in LDS) into obs slots 1..K: ascending
+// squared distance, ties -> lower index (the canonical order for misc.py:20-25); K >= N-1: all
+// others in index order.
 template <int GW, int OD>
-__device__ __forceinline__ void write_neighbour_obs(int N, int Knb, int ag, bool lane_ok, float x, float y,
-                                                    const float (&own)[OD], float *obs_row) {
+__device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb, int ag, int gbase, bool lane_ok,
+                                                    float x, float y, float *obs_row) {
     float d[GW - 1];
-    float nb[GW - 1][OD];
     bool ok[GW - 1];
     int rank[GW - 1];
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
-        const float px = xor_lane<K>(x), py = xor_lane<K>(y);
-        const float dx = px - x, dy = py - y;
-        d[K - 1] = norm2_spec(dx, dy);
+        const float2 pxy = *reinterpret_cast<const float2 *>(&lds.own[gbase + (ag ^ K)][0]);  // partner's (x, y)
+        const float dx = pxy.x - x, dy = pxy.y - y;
+        d[K - 1] = dx * dx + dy * dy;
         ok[K - 1] = lane_ok & ((ag ^ K) < N);
         rank[K - 1] = 0;
-#pragma unroll
-        for (int c = 0; c < OD; ++c) nb[K - 1][c] = xor_lane<K>(own[c]);
     });
     const bool all_others = Knb >= N - 1;
     // rank of partner K among the valid partners: one comparison per unordered pair (Q < K)
@@ -342,7 +365,6 @@ __device__ __forceinline__ void write_neighbour_obs(int N, int Knb, int ag, bool
         constexpr int K = decltype(KK)::value;
         static_for<1, K>([&](auto QQ) {
             constexpr int Q = decltype(QQ)::value;
-            // is Q ahead of K?  distance first, then the lower agent index
             const bool q_first = (d[Q - 1] < d[K - 1]) | ((d[Q - 1] == d[K - 1]) & ((ag ^ Q) < (ag ^ K)));
             const bool both = ok[Q - 1] & ok[K - 1];
             rank[K - 1] += (both & q_first) ? 1 : 0;
@@ -355,17 +377,35 @@ __device__ __forceinline__ void write_neighbour_obs(int N, int Knb, int ag, bool
         const int slot = all_others ? (j < ag ? j : j - 1) : rank[K - 1];
         if (ok[K - 1] & (all_others | (slot < Knb))) {
             float *o = obs_row + (slot + 1) * OD;
+            const float *src = &lds.own[gbase + j][0];
+            if constexpr (OD == 4) {
+                *reinterpret_cast<float4 *>(o) = *reinterpret_cast<const float4 *>(src);
+            } else {
 #pragma unroll
-            for (int c = 0; c < OD; ++c) o[c] = nb[K - 1][c];
+                for (int c = 0; c < OD; ++c) o[c] = src[c];
+            }
         }
     });
 }
+
+// Diagnostic build only (-DRG_STAMPS, tools/stamp_probe.py): wave-cycle stamps of the step's
+// phases, written over io.qp_sweeps of the wave's first 8 envs.  No stamp executes in the
+// shipped library.
+#ifdef RG_STAMPS
+#define RG_STAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
+#else
+#define RG_STAMP(i)
+#endif
 
 // ------------------------------------------------------------------ the step kernel
 template <int SCN, int GW, bool OBS_ONLY>
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     constexpr int EPW = WAVE / GW;  // envs per wave
-    __shared__ Lds lds;
+#ifdef RG_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    __shared__ Lds<GW> lds;
     const rg_scenario_params &p = a.p;
     const Consts k = make_consts(p);
     const int N = p.n_agents;
@@ -378,72 +418,117 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     const bool lane_ok = env_ok && ag < N;
     const size_t eN = static_cast<size_t>(e) * N;
 
-    // ---- loads (coalesced: a wave covers EPW consecutive envs = one contiguous span per array)
+    // ---- loads, all issued up front (coalesced: a wave covers EPW consecutive envs = one
+    // contiguous span per array); what the epilogue needs is fetched now so its latency is hidden
     float x = 0.0f, y = 0.0f, th = 0.0f, carry = 0.0f;
     int act = 4;
+    int steps = 0;
+    float agent_step = 0.0f, sr = 0.0f, cr = 0.0f;
+    float st_ret = 0.0f, st_sum = 0.0f;
+    int st_cnt = 0, st_steps = 0;
+    const bool stats = (!OBS_ONLY) && a.st.ep_return != nullptr;
     if (lane_ok) {
         const float *X = a.st.poses + eN * 3;
         x = X[ag];
         y = X[N + ag];
         th = X[2 * N + ag];
+        agent_step = p.agent_step[ag];
+        if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
+            sr = p.sensing_radius[ag];
+            cr = p.capture_radius[ag];
+        }
         if constexpr (!OBS_ONLY) {
             carry = a.st.carry_dist[eN + ag];
             act = a.actions[eN + ag];
         }
     }
-    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {  // stage the env's prey block in LDS
+    if (env_ok) {
+        steps = a.st.episode_steps[e] + (OBS_ONLY ? 0 : 1);
+        if (stats && ag == 0) {
+            st_ret = a.st.ep_return[e];
+            st_sum = a.st.done_return_sum[e];
+            st_cnt = a.st.done_count[e];
+            st_steps = a.st.done_steps_sum[e];
+        }
+    }
+    // scenario state
+    uint32_t sen_lo = 0, sen_hi = 0, cap_lo = 0, cap_hi = 0;  // PCP prey flags as bit masks (P <= 64)
+    uint8_t loaded = 0;                                      // Warehouse
+    int load = 0, zone0 = 0, zone1 = 0;                      // MaterialTransport
+    int msg[4] = {0, 0, 0, 0};
+    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
         if (env_ok) {
             for (int i = ag; i < 2 * P; i += GW) lds.prey[g][i] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + i];
             for (int i = ag; i < P; i += GW) {
-                lds.sensed[g][i] = a.st.prey_sensed[static_cast<size_t>(e) * P + i];
-                lds.captured[g][i] = a.st.prey_captured[static_cast<size_t>(e) * P + i];
+                const uint32_t sb = a.st.prey_sensed[static_cast<size_t>(e) * P + i] != 0;
+                const uint32_t cb = a.st.prey_captured[static_cast<size_t>(e) * P + i] != 0;
+                if (i < 32) {
+                    sen_lo |= sb << i;
+                    cap_lo |= cb << i;
+                } else {
+                    sen_hi |= sb << (i - 32);
+                    cap_hi |= cb << (i - 32);
+                }
             }
         }
+        sen_lo = group_or<GW>(sen_lo);
+        cap_lo = group_or<GW>(cap_lo);
+        if (P > 32) {
+            sen_hi = group_or<GW>(sen_hi);
+            cap_hi = group_or<GW>(cap_hi);
+        }
+    } else if constexpr (SCN == RG_SCN_WAREHOUSE) {
+        if (lane_ok) loaded = a.st.loaded[eN + ag];
+    } else {
+        if (env_ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                msg[i] = a.st.messages[4 * e + i];
+                if constexpr (!OBS_ONLY)
+                    if (i < N) msg[i] = a.actions[eN + i] % 4;  // MaterialTransport.py:119-120
+            }
+            zone0 = a.st.zone_load[2 * e];
+            zone1 = a.st.zone_load[2 * e + 1];
+        }
+        if (lane_ok) load = a.st.load[eN + ag];
     }
 
     int viol = 0, max_sweeps = 0;
     float dist = 0.0f;
     if constexpr (!OBS_ONLY) {
+#ifdef RG_STAMPS
+        asm volatile("" ::"v"(x), "v"(y), "v"(th), "v"(carry), "v"(act));
+#endif
+        RG_STAMP(0);  // inputs loaded
         // ---- a1 goal generation (agent.py:48-76, warehouse.py:19-45, MaterialTransport.py:19-46)
         float gx = x, gy = y;
         {
             const int mv = (SCN == RG_SCN_MATERIAL_TRANSPORT) ? act / 4 : act;
-            const float sd = p.agent_step[ag];
-            if (mv == 0) {
-                const float t = gx - sd;
-                gx = t > p.left ? t : p.left;
-                gy = clamp_spec(gy, p.up, p.down);
-            } else if (mv == 1) {
-                const float t = gx + sd;
-                gx = t < p.right ? t : p.right;
-                gy = clamp_spec(gy, p.up, p.down);
-            } else if (mv == 2) {
-                gx = clamp_spec(gx, p.left, p.right);
-                const float t = gy - sd;
-                gy = t > p.up ? t : p.up;
-            } else if (mv == 3) {
-                gx = clamp_spec(gx, p.left, p.right);
-                const float t = gy + sd;
-                gy = t < p.down ? t : p.down;
-            } else {
-                gx = clamp_spec(gx, p.left, p.right);
-                gy = clamp_spec(gy, p.up, p.down);
-            }
+            const float sd = agent_step;
+            const float cgx = clamp_spec(gx, p.left, p.right), cgy = clamp_spec(gy, p.up, p.down);
+            const float lft = (gx - sd) > p.left ? (gx - sd) : p.left;
+            const float rgt = (gx + sd) < p.right ? (gx + sd) : p.right;
+            const float upw = (gy - sd) > p.up ? (gy - sd) : p.up;
+            const float dwn = (gy + sd) < p.down ? (gy + sd) : p.down;
+            gx = mv == 0 ? lft : mv == 1 ? rgt : cgx;
+            gy = mv == 2 ? upw : mv == 3 ? dwn : cgy;
         }
         // ---- a2 roboEnv.step (utilities/roboEnv.py:52-94), float spec of oracle/oracle_core.h, one
         // CONTROLLER PERIOD (<= 15 sub-steps with v, w held) at a time: theta and dist_travelled
         // advance once per period by fma; inside the period only x, y and (cos, sin) move.
         //
-        // _validate every sub-step: the exact test (7 DPP rounds of float math) runs only in a rare
-        // wave-uniform branch.  The common path is a conservative integer pre-test on positions
-        // quantised to int16 pairs (4 m <-> 32767, LSB 0.12 mm): one DPP + v_pk_sub_i16 + v_dot2 per
-        // pair round, with a 4 LSB margin on the distance so it can never miss a collision the float
-        // test would flag.  Absent lanes / finished envs sit on far-apart ghost points.
+        // _validate every sub-step: the exact test (GW-1 DPP rounds of float math) runs only in a
+        // rare wave-uniform branch.  The common path is a conservative integer pre-test on the
+        // collision points quantised to int16 pairs (4 m <-> 32767, LSB 0.12 mm): per pair round one
+        // DPP + v_pk_sub_i16 + v_dot2, with a 4 LSB margin on the distance so it can never miss a
+        // collision the float test would flag.  Absent lanes / finished envs sit on far-apart ghost
+        // points.  CHUNK sub-steps are advanced and tested together: their test chains are
+        // independent, which is the only ILP a single wavefront has here.
         const float lim = __builtin_sqrtf(k.coll_lim2);
         const float lq = __builtin_fmaf(lim, 8191.75f, 4.0f);
         const int thr_q = static_cast<int>(lq * lq) + 1;
-        const int ghost_q = (32767 & 0xFFFF) | (((-28000 + 3500 * ag) & 0xFFFF) << 16);  // >= 0.43 m apart, > 2 m from the arena
+        const int ghost_q = (32767 & 0xFFFF) | (((-28000 + 3500 * ag) & 0xFFFF) << 16);  // >= 0.43 m apart, > 2 m off
         float v = 0.0f, w = 0.0f, s = 0.0f, c = 1.0f;
         float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
         bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
@@ -458,49 +543,84 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             const float dtv = k.dt * v, dtw = k.dt * w;
             float sd, cd;
             sincos_spec(dtw, sd, cd);
-            int n_exec = n;           // sub-steps this env executes in this period
+            if (it0 == 0) RG_STAMP(1);  // first controller done
+            int n_exec = n;             // sub-steps this env executes in this period
             bool died_now = false;
-            for (int j = 0; j < n; ++j) {
-                // a10 _validate on the pre-update poses
-                const bool bnd = lane_ok & !dead & ((x < k.xmin) | (x > k.xmax) | (y < k.ymin) | (y > k.ymax));
-                const float fx = __builtin_fmaf(k.coll_off, c, x), fy = __builtin_fmaf(k.coll_off, s, y);
-                const int q_real = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pknorm_i16(fx * 0.25f, fy * 0.25f));
-                const int q = (lane_ok & !dead) ? q_real : ghost_q;
-                int dmin = 0x7FFFFFFF;
-                static_for<1, GW>([&](auto KK) {
-                    constexpr int K = decltype(KK)::value;
-                    const short2v dq = __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, q),
-                                                                     __builtin_bit_cast(short2v, xor_lane_i<K>(q)));
-                    const int d2 = __builtin_amdgcn_sdot2(dq, dq, 0, false);
-                    dmin = d2 < dmin ? d2 : dmin;
+
+            // C sub-steps starting at sub-step j0 of this period
+            auto run_chunk = [&](auto CC, int j0) {
+                constexpr int C = decltype(CC)::value;
+                const float x0 = x, y0 = y, c0 = c, s0 = s;
+                const bool live = lane_ok & !dead;
+                int q[C];
+                float bx_lo = x, bx_hi = x, by_lo = y, by_hi = y;  // extent of the pre-update positions
+                static_for<0, C>([&](auto UU) {
+                    constexpr int u = decltype(UU)::value;
+                    if constexpr (u > 0) {
+                        bx_lo = fminf(bx_lo, x);
+                        bx_hi = fmaxf(bx_hi, x);
+                        by_lo = fminf(by_lo, y);
+                        by_hi = fmaxf(by_hi, y);
+                    }
+                    const float fx = __builtin_fmaf(k.coll_off, c, x), fy = __builtin_fmaf(k.coll_off, s, y);
+                    const int qr = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pknorm_i16(fx * 0.25f, fy * 0.25f));
+                    q[u] = live ? qr : ghost_q;
+                    // Euler step (Appendix A.4); rotate (cos, sin) by dt*w
+                    x = __builtin_fmaf(c, dtv, x);
+                    y = __builtin_fmaf(s, dtv, y);
+                    const float cn = __builtin_fmaf(c, cd, -(s * sd));
+                    const float sn = __builtin_fmaf(s, cd, c * sd);
+                    c = cn;
+                    s = sn;
                 });
-                const bool near = dmin <= thr_q;
-                if (penalize && __any(near | bnd)) {  // rare: exact float test (roboEnv.py:82-94)
-                    bool col = false;
+                int dmin = 0x7FFFFFFF;
+                static_for<0, C>([&](auto UU) {
+                    constexpr int u = decltype(UU)::value;
                     static_for<1, GW>([&](auto KK) {
                         constexpr int K = decltype(KK)::value;
-                        const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
-                        col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
+                        const short2v dq = __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, q[u]),
+                                                                         __builtin_bit_cast(short2v, xor_lane_i<K>(q[u])));
+                        int d2;
+                        asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2) : "v"(dq));
+                        dmin = d2 < dmin ? d2 : dmin;
                     });
-                    col = col & lane_ok & !dead;
-                    const int code = (group_any<GW>(col, gbase) ? 1 : 0) | (group_any<GW>(bnd, gbase) ? 2 : 0);
-                    if (env_ok & !dead & (code != 0)) {
-                        viol = code;
-                        n_exec = j + 1;
-                        died_now = true;
-                        dead = true;
-                        fin_x = __builtin_fmaf(c, dtv, x);  // this sub-step is still integrated
-                        fin_y = __builtin_fmaf(s, dtv, y);
+                });
+                const bool bnd_any = live & ((bx_lo < k.xmin) | (bx_hi > k.xmax) | (by_lo < k.ymin) | (by_hi > k.ymax));
+                if (penalize && __any((dmin <= thr_q) | bnd_any)) {
+                    // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
+                    float rx = x0, ry = y0, rc = c0, rs = s0;
+                    for (int u = 0; u < C; ++u) {
+                        const bool bnd = lane_ok & !dead & ((rx < k.xmin) | (rx > k.xmax) | (ry < k.ymin) | (ry > k.ymax));
+                        const float fx = __builtin_fmaf(k.coll_off, rc, rx), fy = __builtin_fmaf(k.coll_off, rs, ry);
+                        bool col = false;
+                        static_for<1, GW>([&](auto KK) {
+                            constexpr int K = decltype(KK)::value;
+                            const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
+                            col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
+                        });
+                        col = col & lane_ok & !dead;
+                        const int code = (group_any<GW>(col, gbase) ? 1 : 0) | (group_any<GW>(bnd, gbase) ? 2 : 0);
+                        rx = __builtin_fmaf(rc, dtv, rx);  // the violating sub-step is still integrated
+                        ry = __builtin_fmaf(rs, dtv, ry);
+                        if (env_ok & !dead & (code != 0)) {
+                            viol = code;
+                            n_exec = j0 + u + 1;
+                            died_now = true;
+                            dead = true;
+                            fin_x = rx;
+                            fin_y = ry;
+                        }
+                        const float cn = __builtin_fmaf(rc, cd, -(rs * sd));
+                        const float sn = __builtin_fmaf(rs, cd, rc * sd);
+                        rc = cn;
+                        rs = sn;
                     }
                 }
-                // Euler step (Appendix A.4); rotate (cos, sin) by dt*w
-                x = __builtin_fmaf(c, dtv, x);
-                y = __builtin_fmaf(s, dtv, y);
-                const float cn = __builtin_fmaf(c, cd, -(s * sd));
-                const float sn = __builtin_fmaf(s, cd, c * sd);
-                c = cn;
-                s = sn;
-            }
+            };
+            int j = 0;
+            for (; j + CHUNK <= n; j += CHUNK) run_chunk(std::integral_constant<int, CHUNK>{}, j);
+            for (; j < n; ++j) run_chunk(std::integral_constant<int, 1>{}, j);
+
             // period end: heading and distance for the sub-steps this env executed
             const bool upd = env_ok & (!dead | died_now);
             const float ne = static_cast<float>(n_exec);
@@ -508,6 +628,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             th = upd ? wrap_spec(__builtin_fmaf(ne, dtw, th)) : th;
             acc = upd ? __builtin_fmaf(ne, adv, acc) : acc;
             last = upd ? adv : last;
+            if (it0 == 0) RG_STAMP(2);  // first period done
             if (!__any(env_ok & !dead)) break;
         }
         if (dead) {
@@ -516,64 +637,91 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         }
         dist = viol ? acc : acc - last;
         carry = last;
+        RG_STAMP(3);  // all periods done
     }
-
-    __syncthreads();  // LDS prey block visible (single-wave workgroup: compiles to waitcnt + s_barrier)
 
     // ---- scenario epilogue
     const int D = p.obs_dim;
     float *obs_row = a.io.obs + (eN + ag) * D;
-    int steps = 0;
-    if (env_ok) steps = a.st.episode_steps[e] + (OBS_ONLY ? 0 : 1);
     bool done = false;
     int remaining = -1;
     float reward = 0.0f;
 
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
-        const float sr = p.sensing_radius[ag], cr = p.capture_radius[ag];
-        int unseen0 = 0, left0 = 0, unseen1 = 0, left1 = 0;
+        const float sr2 = sr * sr, cr2 = cr * cr;
+        __syncthreads();  // LDS prey block visible (single-wave workgroup: waitcnt + s_barrier)
+        uint32_t nsen_lo = sen_lo, nsen_hi = sen_hi, ncap_lo = cap_lo, ncap_hi = cap_hi;
+        if constexpr (!OBS_ONLY) {  // a11 _update_tracking_and_locations (PredatorCapturePrey.py:72-95)
+            uint32_t s_lo = 0, s_hi = 0, c_lo = 0, c_hi = 0;  // prey this agent senses / could capture
+            const bool acts = lane_ok & (act == 4);
+            for (int i = 0; i < P; ++i) {
+                const float2 pl = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * i]);
+                const float dx = x - pl.x, dy = y - pl.y;
+                const float d2 = dx * dx + dy * dy;
+                const uint32_t sb = (lane_ok & (d2 <= sr2)) ? 1u : 0u, cb = (acts & (d2 <= cr2)) ? 1u : 0u;
+                if (i < 32) {
+                    s_lo |= sb << i;
+                    c_lo |= cb << i;
+                } else {
+                    s_hi |= sb << (i - 32);
+                    c_hi |= cb << (i - 32);
+                }
+            }
+            s_lo = group_or<GW>(s_lo);
+            c_lo = group_or<GW>(c_lo);
+            nsen_lo = sen_lo | (s_lo & ~cap_lo);          // sensed: any agent in range, prey not yet captured
+            ncap_lo = cap_lo | (nsen_lo & c_lo & ~cap_lo);  // captured: sensed and a 'no_action' agent in range
+            if (P > 32) {
+                s_hi = group_or<GW>(s_hi);
+                c_hi = group_or<GW>(c_hi);
+                nsen_hi = sen_hi | (s_hi & ~cap_hi);
+                ncap_hi = cap_hi | (nsen_hi & c_hi & ~cap_hi);
+            }
+            if (env_ok) {
+                for (int i = ag; i < P; i += GW) {
+                    const uint32_t sw_ = i < 32 ? nsen_lo >> i : nsen_hi >> (i - 32);
+                    const uint32_t cw_ = i < 32 ? ncap_lo >> i : ncap_hi >> (i - 32);
+                    a.st.prey_sensed[static_cast<size_t>(e) * P + i] = sw_ & 1u;
+                    a.st.prey_captured[static_cast<size_t>(e) * P + i] = cw_ & 1u;
+                }
+            }
+        }
+        // a13 own observation: nearest uncaptured prey within the agent's own sensing radius
         float closest = -1.0f, qx = -5.0f, qy = -5.0f;
         for (int i = 0; i < P; ++i) {
-            const float plx = lds.prey[g][2 * i], ply = lds.prey[g][2 * i + 1];
-            const float d = norm2_spec(x - plx, y - ply);
-            bool sen = lds.sensed[g][i] != 0, cap = lds.captured[g][i] != 0;
-            unseen0 += !sen;
-            left0 += !cap;
-            if constexpr (!OBS_ONLY) {  // a11 _update_tracking_and_locations
-                const bool any_s = group_any<GW>(lane_ok && d <= sr, gbase);
-                const bool any_c = group_any<GW>(lane_ok && act == 4 && d <= cr, gbase);
-                if (!cap) {
-                    if (!sen && any_s) sen = true;
-                    if (sen && any_c) cap = true;
-                }
-                if (lane_ok && ag == 0) {
-                    a.st.prey_sensed[static_cast<size_t>(e) * P + i] = sen;
-                    a.st.prey_captured[static_cast<size_t>(e) * P + i] = cap;
-                }
-            }
-            unseen1 += !sen;
-            left1 += !cap;
-            // a13 own observation: nearest uncaptured prey within the agent's own sensing radius
-            if (!cap && d <= sr && (d < closest || closest == -1.0f)) {
-                qx = plx;
-                qy = ply;
-                closest = d;
-            }
+            const float2 pl = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * i]);
+            const float dx = x - pl.x, dy = y - pl.y;
+            const float d2 = dx * dx + dy * dy;
+            const bool cap = ((i < 32 ? ncap_lo >> i : ncap_hi >> (i - 32)) & 1u) != 0;
+            const bool take = !cap & (d2 <= sr2) & ((d2 < closest) | (closest == -1.0f));
+            qx = take ? pl.x : qx;
+            qy = take ? pl.y : qy;
+            closest = take ? d2 : closest;
         }
-        if (p.capability_aware) {
-            const float own[6] = {x, y, qx, qy, sr, cr};
+        const int od = p.capability_aware ? 6 : 4;
+        lds.own[lane][0] = x;
+        lds.own[lane][1] = y;
+        lds.own[lane][2] = qx;
+        lds.own[lane][3] = qy;
+        lds.own[lane][4] = sr;
+        lds.own[lane][5] = cr;
+        __syncthreads();
+        if (od == 6) {
             if (lane_ok) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) obs_row[c] = own[c];
+                for (int cc = 0; cc < 6; ++cc) obs_row[cc] = lds.own[lane][cc];
             }
-            write_neighbour_obs<GW, 6>(N, p.num_neighbors, ag, lane_ok, x, y, own, obs_row);
+            write_neighbour_obs<GW, 6>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         } else {
-            const float own[4] = {x, y, qx, qy};
             if (lane_ok) *reinterpret_cast<float4 *>(obs_row) = make_float4(x, y, qx, qy);
-            write_neighbour_obs<GW, 4>(N, p.num_neighbors, ag, lane_ok, x, y, own, obs_row);
+            write_neighbour_obs<GW, 4>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         }
-        if constexpr (!OBS_ONLY) {  // a14 reward / termination
+        if constexpr (!OBS_ONLY) {  // a14 reward / termination (PredatorCapturePrey.py:155-176, 209-216)
+            const int unseen0 = P - __builtin_popcount(sen_lo) - __builtin_popcount(sen_hi);
+            const int left0 = P - __builtin_popcount(cap_lo) - __builtin_popcount(cap_hi);
+            const int unseen1 = P - __builtin_popcount(nsen_lo) - __builtin_popcount(nsen_hi);
+            const int left1 = P - __builtin_popcount(ncap_lo) - __builtin_popcount(ncap_hi);
             if (viol) {
                 reward = p.violation_reward;
                 done = true;
@@ -588,22 +736,23 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 }
             }
         }
-    } else if constexpr (SCN == RG_SCN_WAREHOUSE) {  // a15
-        uint8_t loaded = 0;
-        if (lane_ok) loaded = a.st.loaded[eN + ag];
-        const float own[3] = {x, y, loaded ? 1.0f : 0.0f};
+    } else if constexpr (SCN == RG_SCN_WAREHOUSE) {  // a15 (warehouse.py:102-178): obs BEFORE the reward mutates `loaded`
+        lds.own[lane][0] = x;
+        lds.own[lane][1] = y;
+        lds.own[lane][2] = loaded ? 1.0f : 0.0f;
+        __syncthreads();
         if (lane_ok) {
-            obs_row[0] = own[0];
-            obs_row[1] = own[1];
-            obs_row[2] = own[2];
+            obs_row[0] = x;
+            obs_row[1] = y;
+            obs_row[2] = loaded ? 1.0f : 0.0f;
         }
-        write_neighbour_obs<GW, 3>(N, p.num_neighbors, ag, lane_ok, x, y, own, obs_row);
+        write_neighbour_obs<GW, 3>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         if constexpr (!OBS_ONLY) {
             if (viol) {
                 reward = p.violation_reward;
                 done = true;
             } else {
-                const bool green = (ag % 2) == 0;
+                const bool green = (ag % 2) == 0;  // warehouse.py:63-65
                 if (loaded) {
                     if (x < -1.5f + p.goal_width && ((green && y > 0.0f) || (!green && y <= 0.0f))) {
                         reward = p.unload_reward;
@@ -619,20 +768,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 if (lane_ok) a.st.loaded[eN + ag] = loaded;
             }
         }
-    } else {  // a16 MaterialTransport
-        int msg[4] = {0, 0, 0, 0};
-        int zone0 = 0, zone1 = 0, load = 0;
-        if (env_ok) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                msg[i] = a.st.messages[4 * e + i];
-                if constexpr (!OBS_ONLY)
-                    if (i < N) msg[i] = a.actions[eN + i] % 4;
-            }
-            zone0 = a.st.zone_load[2 * e];
-            zone1 = a.st.zone_load[2 * e + 1];
-        }
-        if (lane_ok) load = a.st.load[eN + ag];
+    } else {  // a16 MaterialTransport (MaterialTransport.py:113-189)
         if (lane_ok) {
             obs_row[0] = x;
             obs_row[1] = y;
@@ -643,7 +779,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             for (int i = 0; i < 4; ++i) obs_row[5 + i] = static_cast<float>(msg[i]);
             if (p.capability_aware) {
                 obs_row[9] = static_cast<float>(p.torque[ag]);
-                obs_row[10] = p.agent_step[ag];
+                obs_row[10] = agent_step;
             }
         }
         if constexpr (!OBS_ONLY) {
@@ -659,6 +795,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 // every lane replays the env's sequential loop from the LDS copy
                 reward = p.time_penalty;
                 const float egw = p.end_goal_width;
+                const float zr2 = p.zone1_radius * p.zone1_radius;
                 bool any_load = false;
                 for (int j = 0; j < N; ++j) {
                     const float jx = lds.ax[gbase + j], jy = lds.ay[gbase + j];
@@ -679,7 +816,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                                 zone1 = 0;
                             }
                             reward = reward + static_cast<float>(jl) * p.load_multiplier;
-                        } else if (norm2_spec(jx, jy) <= p.zone1_radius) {
+                        } else if (jx * jx + jy * jy <= zr2) {
                             if (zone0 > tq) {
                                 jl = tq;
                                 zone0 -= tq;
@@ -712,10 +849,12 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         }
     }
 
+    RG_STAMP(4);  // scenario epilogue computed
     if constexpr (!OBS_ONLY) {
         // sum of the agents' rewards in agent order (only read when shared_reward == 0)
         float rsum = 0.0f;
-        if (a.st.ep_return && !p.shared_reward) {
+        if (stats && !p.shared_reward) {
+            __syncthreads();
             lds.ax[lane] = lane_ok ? reward : 0.0f;
             __syncthreads();
             for (int j = 0; j < N; ++j) rsum = rsum + lds.ax[gbase + j];
@@ -731,12 +870,12 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             a.io.dist_travelled[eN + ag] = dist;
             if (ag == 0) {
                 a.st.episode_steps[e] = steps;
-                if (a.st.ep_return) {  // misc.py:178-185: episodeReward += reward[0] | sum(reward)
-                    float ret = a.st.ep_return[e] + (p.shared_reward ? reward : rsum);
+                if (stats) {  // misc.py:178-185: episodeReward += reward[0] | sum(reward)
+                    float ret = st_ret + (p.shared_reward ? reward : rsum);
                     if (done) {
-                        a.st.done_return_sum[e] = a.st.done_return_sum[e] + ret;
-                        a.st.done_count[e] = a.st.done_count[e] + 1;
-                        a.st.done_steps_sum[e] = a.st.done_steps_sum[e] + steps;
+                        a.st.done_return_sum[e] = st_sum + ret;
+                        a.st.done_count[e] = st_cnt + 1;
+                        a.st.done_steps_sum[e] = st_steps + steps;
                         ret = 0.0f;
                     }
                     a.st.ep_return[e] = ret;
@@ -747,21 +886,35 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 if (a.io.qp_sweeps) a.io.qp_sweeps[e] = max_sweeps;
             }
         }
-        // ---- fused auto-reset of finished envs (scenario.reset(), not hot: ~1/80 steps)
-        if (a.auto_reset) {
-            __syncthreads();  // this wave's state stores are issued; the resetting lane rewrites them
-            if (lane_ok && ag == 0 && done) reset_env<SCN>(a, e, lds.perm[g]);
+        RG_STAMP(5);  // outputs stored
+        // ---- fused auto-reset of finished envs (scenario.reset(); ~1 env in 70 per step)
+        if (a.auto_reset && __any(env_ok & done)) {
+            __syncthreads();  // the wave's state stores are issued before the resetting lanes rewrite them
+            reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done);
         }
+        RG_STAMP(6);  // reset done
+#ifdef RG_STAMPS
+        if (lane == 0 && a.io.qp_sweeps) {
+            stamps[7] = max_sweeps;
+            for (int i = 0; i < 8; ++i)
+                if (blockIdx.x * EPW + i < a.E) a.io.qp_sweeps[blockIdx.x * EPW + i] = stamps[i];
+        }
+#endif
     }
 }
 
-template <int SCN>
+template <int SCN, int GW>
 __global__ __launch_bounds__(WAVE) void reset_kernel(const KernelArgs a) {
-    __shared__ uint8_t perm[WAVE][64];
-    const int e = blockIdx.x * WAVE + threadIdx.x;
-    if (e >= a.E) return;
-    if (a.reset_mask && !a.reset_mask[e]) return;
-    reset_env<SCN>(a, e, perm[threadIdx.x]);
+    constexpr int EPW = WAVE / GW;
+    __shared__ Lds<GW> lds;
+    const int lane = threadIdx.x;
+    const int ag = lane & (GW - 1);
+    const int g = lane / GW;
+    const int e = blockIdx.x * EPW + g;
+    const bool env_ok = e < a.E;
+    const bool want = env_ok && (a.reset_mask == nullptr || a.reset_mask[e] != 0);
+    if (!__any(want)) return;
+    reset_group<SCN, GW>(a, lds, e, g, ag, want);
 }
 
 }  // namespace rg
@@ -769,22 +922,25 @@ __global__ __launch_bounds__(WAVE) void reset_kernel(const KernelArgs a) {
 // ------------------------------------------------------------------ host side: launch dispatch
 namespace rg {
 
+static int group_width(int N) { return N <= 4 ? 4 : N <= 8 ? 8 : 16; }
+
 template <int SCN, bool OBS_ONLY>
 static hipError_t launch_step_scn(const KernelArgs &a, hipStream_t stream) {
-    const int N = a.p.n_agents;
-    if (N <= 4) {
-        constexpr int GW = 4;
-        const int grid = (a.E + WAVE / GW - 1) / (WAVE / GW);
-        hipLaunchKernelGGL((step_kernel<SCN, GW, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
-    } else if (N <= 8) {
-        constexpr int GW = 8;
-        const int grid = (a.E + WAVE / GW - 1) / (WAVE / GW);
-        hipLaunchKernelGGL((step_kernel<SCN, GW, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
-    } else {
-        constexpr int GW = 16;
-        const int grid = (a.E + WAVE / GW - 1) / (WAVE / GW);
-        hipLaunchKernelGGL((step_kernel<SCN, GW, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
-    }
+    const int gw = group_width(a.p.n_agents);
+    const int grid = (a.E + WAVE / gw - 1) / (WAVE / gw);
+    if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if (gw == 8) hipLaunchKernelGGL((step_kernel<SCN, 8, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else hipLaunchKernelGGL((step_kernel<SCN, 16, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <int SCN>
+static hipError_t launch_reset_scn(const KernelArgs &a, hipStream_t stream) {
+    const int gw = group_width(a.p.n_agents);
+    const int grid = (a.E + WAVE / gw - 1) / (WAVE / gw);
+    if (gw == 4) hipLaunchKernelGGL((reset_kernel<SCN, 4>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if (gw == 8) hipLaunchKernelGGL((reset_kernel<SCN, 8>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else hipLaunchKernelGGL((reset_kernel<SCN, 16>), dim3(grid), dim3(WAVE), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -805,21 +961,16 @@ hipError_t launch_step(const KernelArgs &a, bool obs_only, hipStream_t stream) {
 }
 
 hipError_t launch_reset(const KernelArgs &a, hipStream_t stream) {
-    const int grid = (a.E + WAVE - 1) / WAVE;
     switch (a.p.scenario) {
         case RG_SCN_PREDATOR_CAPTURE_PREY:
-            hipLaunchKernelGGL((reset_kernel<RG_SCN_PREDATOR_CAPTURE_PREY>), dim3(grid), dim3(WAVE), 0, stream, a);
-            break;
+            return launch_reset_scn<RG_SCN_PREDATOR_CAPTURE_PREY>(a, stream);
         case RG_SCN_WAREHOUSE:
-            hipLaunchKernelGGL((reset_kernel<RG_SCN_WAREHOUSE>), dim3(grid), dim3(WAVE), 0, stream, a);
-            break;
+            return launch_reset_scn<RG_SCN_WAREHOUSE>(a, stream);
         case RG_SCN_MATERIAL_TRANSPORT:
-            hipLaunchKernelGGL((reset_kernel<RG_SCN_MATERIAL_TRANSPORT>), dim3(grid), dim3(WAVE), 0, stream, a);
-            break;
+            return launch_reset_scn<RG_SCN_MATERIAL_TRANSPORT>(a, stream);
         default:
             return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 }  // namespace rg

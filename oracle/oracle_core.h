@@ -84,11 +84,18 @@ static inline float FN(wrap)(float t) {
 #define SINCOS(t, s, c) FN(sincos)((t), (s), (c))
 #define ATAN2(y, x) FN(atan2)((y), (x))
 #define SQRT(v) __builtin_sqrtf(v)
+/* float spec: range tests and nearest-neighbour / nearest-prey ordering compare SQUARED distances
+ * (d2 <= r*r, d2_a < d2_b): the same decisions as the reference's norm() <= r except within an ulp
+ * of the threshold, and no sqrt in the scenario epilogue */
+#define DIST(d2) (d2)
+#define RADIUS(r) ((r) * (r))
 #else
 #define SINCOS(t, s, c) do { *(s) = sin(t); *(c) = cos(t); } while (0)
 #define ATAN2(y, x) atan2((y), (x))
 #define WRAP(t) atan2(sin(t), cos(t))
 #define SQRT(v) sqrt(v)
+#define DIST(d2) sqrt(d2)
+#define RADIUS(r) (r)
 #endif
 
 #define R(v) ((REAL)(v))
@@ -284,7 +291,7 @@ static int FN(neighbours)(int N, int K, int a, const REAL *x, const REAL *y, int
     REAL d[ORC_MAXN];
     for (int j = 0; j < N; ++j) {
         REAL dx = x[j] - x[a], dy = y[j] - y[a];
-        d[j] = SQRT(dx * dx + dy * dy);
+        d[j] = DIST(dx * dx + dy * dy); /* float spec: squared distances (same order, no sqrt) */
     }
     for (int j = 0; j < N; ++j) {
         if (j == a) continue;
@@ -469,20 +476,20 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
         for (int i = 0; i < P; ++i)
             for (int a = 0; a < N; ++a) {
                 REAL dx = x[a] - pl[2 * i], dy = y[a] - pl[2 * i + 1];
-                dpa[i][a] = SQRT(dx * dx + dy * dy);
+                dpa[i][a] = DIST(dx * dx + dy * dy);
             }
         /* a11 _update_tracking_and_locations (PredatorCapturePrey.py:72-95) */
         for (int i = 0; i < P; ++i) {
             if (captured[i]) continue;
             if (!sensed[i])
                 for (int a = 0; a < N; ++a)
-                    if (dpa[i][a] <= R(p->sensing_radius[a])) {
+                    if (dpa[i][a] <= RADIUS(R(p->sensing_radius[a]))) {
                         sensed[i] = 1;
                         break;
                     }
             if (sensed[i])
                 for (int a = 0; a < N; ++a)
-                    if (act[a] == 4 && dpa[i][a] <= R(p->capture_radius[a])) {
+                    if (act[a] == 4 && dpa[i][a] <= RADIUS(R(p->capture_radius[a]))) {
                         captured[i] = 1;
                         break;
                     }
@@ -500,7 +507,7 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
             for (int i = 0; i < P; ++i) {
                 if (captured[i]) continue;
                 REAL d = dpa[i][a];
-                if (d <= R(p->sensing_radius[a]) && (d < closest || closest == R(-1))) {
+                if (d <= RADIUS(R(p->sensing_radius[a])) && (d < closest || closest == R(-1))) {
                     qx = pl[2 * i];
                     qy = pl[2 * i + 1];
                     closest = d;
@@ -621,7 +628,7 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
                             zone[1] = 0;
                         }
                         r = r + (REAL)load[a] * R(p->load_multiplier);
-                    } else if (SQRT(x[a] * x[a] + y[a] * y[a]) <= R(p->zone1_radius)) {
+                    } else if (DIST(x[a] * x[a] + y[a] * y[a]) <= RADIUS(R(p->zone1_radius))) {
                         if (zone[0] > p->torque[a]) {
                             load[a] = p->torque[a];
                             zone[0] -= p->torque[a];
@@ -679,4 +686,6 @@ int FN(orc_controller)(const orc_params *p, const REAL *poses /*3xN*/, const REA
 #undef ATAN2
 #undef WRAP
 #undef SQRT
+#undef DIST
+#undef RADIUS
 #undef R
