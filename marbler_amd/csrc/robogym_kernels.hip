@@ -146,11 +146,15 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         ux = clip ? ux * sc : ux;
         uy = clip ? uy * sc : uy;
     }
-    // a6 barrier certificate: rows e_ij.(u_j - u_i) <= beta_ij, one per round
+    // a6 barrier certificate: rows e_ij.(u_j - u_i) <= beta_ij, one per round; the exact projection
+    // by Hildreth sweeps with Aitken restarts (algorithm and derivation: oracle/oracle_core.h
+    // barrier_qp).  Per round: f = e/n2, bp = beta/n2, emax = max(|ex|, |ey|); absent pairs have
+    // f = bp = emax = 0 and mu = 0, which makes every update of theirs an exact no-op.
     const float bgain = p.barrier_gain, ugain = p.unsafe_barrier_gain, qp_rtol = p.qp_rtol;
     const int qp_cap = p.qp_max_sweeps;
     const bool has_unsafe = p.barrier_has_unsafe_gain != 0;
-    float ex[GW - 1], ey[GW - 1], beta[GW - 1], rn2[GW - 1], mu[GW - 1];
+    float ex[GW - 1], ey[GW - 1], fx[GW - 1], fy[GW - 1], bp[GW - 1], emax[GW - 1];
+    float mu[GW - 1], muA[GW - 1], muB[GW - 1];
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
         const float pxi = xor_lane<K>(xix), pyi = xor_lane<K>(xiy);
@@ -161,11 +165,14 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         const float b = gain * ((h * h) * h);
         const float n2 = 2.0f * ee;
         const bool ok = lane_ok & ((ag ^ K) < N) & (n2 > 0.0f);
+        const float rn2 = ok ? 1.0f / n2 : 0.0f;
         ex[K - 1] = dx;
         ey[K - 1] = dy;
-        beta[K - 1] = 0.5f * b;
-        rn2[K - 1] = ok ? 1.0f / n2 : 0.0f;
-        mu[K - 1] = 0.0f;
+        fx[K - 1] = dx * rn2;
+        fy[K - 1] = dy * rn2;
+        bp[K - 1] = (0.5f * b) * rn2;
+        emax[K - 1] = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
+        mu[K - 1] = muA[K - 1] = muB[K - 1] = 0.0f;
     });
     {   // "Threshold control inputs before QP"
         const float nrm = norm2_spec(ux, uy);
@@ -174,33 +181,53 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         ux = clip ? ux * sc : ux;
         uy = clip ? uy * sc : uy;
     }
-    // Hildreth sweeps; a group drops out when converged, the wave loops while any group is active
+    const float uhx = ux, uhy = uy;
+    // A group drops out when converged (its lanes are exec-masked for the whole sweep body: groups
+    // are uniform, so an active lane never reads a masked partner); the wave loops while any group
+    // is active.
     bool active = upd;
     int sweeps = 0, my_sweeps = 0;
     while (__any(active)) {
-        float chg = 0.0f;
-        static_for<1, GW>([&](auto KK) {
-            constexpr int K = decltype(KK)::value;
-            // rn2 is 0 for absent pairs and mu starts at 0, so they are no-ops; a converged group is
-            // frozen by zeroing its step (d = 0 -> mn = mu -> delta = 0): same arithmetic as the oracle
-            const float pux = xor_lane<K>(ux), puy = xor_lane<K>(uy);
-            const float r = ex[K - 1] * (pux - ux) + ey[K - 1] * (puy - uy) - beta[K - 1];
-            const float d = r * (active ? rn2[K - 1] : 0.0f);
-            float mn = mu[K - 1] + d;
-            mn = (mn > 0.0f) ? mn : 0.0f;
-            const float delta = mn - mu[K - 1];
-            mu[K - 1] = mn;
-            const float cx = delta * ex[K - 1], cy = delta * ey[K - 1];
-            ux = ux + cx;
-            uy = uy + cy;
-            chg = fmaxf(chg, fmaxf(__builtin_fabsf(cx), __builtin_fabsf(cy)));
-        });
         ++sweeps;
-        my_sweeps = active ? sweeps : my_sweeps;
-        const float um = lane_ok ? fmaxf(__builtin_fabsf(ux), __builtin_fabsf(uy)) : 0.0f;
-        const float gchg = group_max<GW>(chg);
-        const float gum = fmaxf(k.bml, group_max<GW>(um));
-        active = active & (gchg > qp_rtol * gum) & (sweeps < qp_cap);
+        if (active) {
+            float chg = 0.0f;
+            static_for<1, GW>([&](auto KK) {
+                constexpr int K = decltype(KK)::value;
+                muA[K - 1] = muB[K - 1];
+                muB[K - 1] = mu[K - 1];
+                const float pux = xor_lane<K>(ux), puy = xor_lane<K>(uy);
+                const float c0 = mu[K - 1] - bp[K - 1];
+                const float t = __builtin_fmaf(fy[K - 1], puy - uy, c0);
+                float mn = __builtin_fmaf(fx[K - 1], pux - ux, t);
+                mn = (mn > 0.0f) ? mn : 0.0f;
+                const float delta = mn - mu[K - 1];
+                mu[K - 1] = mn;
+                ux = __builtin_fmaf(delta, ex[K - 1], ux);
+                uy = __builtin_fmaf(delta, ey[K - 1], uy);
+                chg = fmaxf(chg, __builtin_fabsf(delta) * emax[K - 1]);
+            });
+            my_sweeps = sweeps;
+            const float um = lane_ok ? fmaxf(__builtin_fabsf(ux), __builtin_fabsf(uy)) : 0.0f;
+            const float gchg = group_max<GW>(chg);
+            const float gum = fmaxf(k.bml, group_max<GW>(um));
+            active = (gchg > qp_rtol * gum) & (sweeps < qp_cap);
+            if (active & ((sweeps & 3) == 3)) {  // Aitken restart of the multipliers, u rebuilt from them
+                float sx = uhx, sy = uhy;
+                static_for<1, GW>([&](auto KK) {
+                    constexpr int K = decltype(KK)::value;
+                    const float d1 = muB[K - 1] - muA[K - 1], d2 = mu[K - 1] - muB[K - 1];
+                    const bool geo = (d1 != 0.0f) & (d2 != 0.0f) & ((d1 > 0.0f) == (d2 > 0.0f)) &
+                                     (__builtin_fabsf(d2) < 0.97f * __builtin_fabsf(d1)) & (emax[K - 1] > 0.0f);
+                    float m = mu[K - 1] - (d2 * d2) / (d2 - d1);
+                    m = (m > 0.0f) ? m : 0.0f;
+                    mu[K - 1] = geo ? m : mu[K - 1];
+                    sx = __builtin_fmaf(mu[K - 1], ex[K - 1], sx);
+                    sy = __builtin_fmaf(mu[K - 1], ey[K - 1], sy);
+                });
+                ux = sx;
+                uy = sy;
+            }
+        }
     }
     // a7 si_to_uni_dyn, a8 set_velocities
     float vv = c * ux + s * uy;
@@ -348,28 +375,48 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
 template <int GW, int OD>
 __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb, int ag, int gbase, bool lane_ok,
                                                     float x, float y, float *obs_row) {
-    float d[GW - 1];
+    // 64-bit sort keys: (bits of the squared distance, partner index) -- non-negative floats order
+    // like their bit patterns, so one unsigned 64-bit compare is the (distance, index) lexicographic
+    // test.  Absent partners get keys above every real one.
+    unsigned long long key[GW - 1];
     bool ok[GW - 1];
     int rank[GW - 1];
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
         const float2 pxy = *reinterpret_cast<const float2 *>(&lds.own[gbase + (ag ^ K)][0]);  // partner's (x, y)
         const float dx = pxy.x - x, dy = pxy.y - y;
-        d[K - 1] = dx * dx + dy * dy;
+        const float d2 = dx * dx + dy * dy;
         ok[K - 1] = lane_ok & ((ag ^ K) < N);
-        rank[K - 1] = 0;
+        const unsigned int hi = ok[K - 1] ? __builtin_bit_cast(unsigned int, d2) : 0xFFFFFFFFu;
+        key[K - 1] = (static_cast<unsigned long long>(hi) << 32) | static_cast<unsigned int>(ag ^ K);
+        rank[K - 1] = GW - 1 - K;  // pairs in which this round is the first element; each lost comparison adds one below
     });
     const bool all_others = Knb >= N - 1;
-    // rank of partner K among the valid partners: one comparison per unordered pair (Q < K)
+    // rank of partner K = number of partners ahead of it: one comparison per unordered pair (Q < K)
     static_for<2, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
         static_for<1, K>([&](auto QQ) {
             constexpr int Q = decltype(QQ)::value;
-            const bool q_first = (d[Q - 1] < d[K - 1]) | ((d[Q - 1] == d[K - 1]) & ((ag ^ Q) < (ag ^ K)));
-            const bool both = ok[Q - 1] & ok[K - 1];
-            rank[K - 1] += (both & q_first) ? 1 : 0;
-            rank[Q - 1] += (both & !q_first) ? 1 : 0;
+            const int q_first = key[Q - 1] < key[K - 1] ? 1 : 0;
+            rank[K - 1] += q_first;
+            rank[Q - 1] -= q_first;
         });
+    });
+    // the rows first (independent LDS reads in flight together), then the predicated stores
+    float row[GW - 1][OD];
+    static_for<1, GW>([&](auto KK) {
+        constexpr int K = decltype(KK)::value;
+        const float *src = &lds.own[gbase + (ag ^ K)][0];
+        if constexpr (OD == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            row[K - 1][0] = v.x;
+            row[K - 1][1] = v.y;
+            row[K - 1][2] = v.z;
+            row[K - 1][3] = v.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < OD; ++c) row[K - 1][c] = src[c];
+        }
     });
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
@@ -377,12 +424,11 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
         const int slot = all_others ? (j < ag ? j : j - 1) : rank[K - 1];
         if (ok[K - 1] & (all_others | (slot < Knb))) {
             float *o = obs_row + (slot + 1) * OD;
-            const float *src = &lds.own[gbase + j][0];
             if constexpr (OD == 4) {
-                *reinterpret_cast<float4 *>(o) = *reinterpret_cast<const float4 *>(src);
+                *reinterpret_cast<float4 *>(o) = make_float4(row[K - 1][0], row[K - 1][1], row[K - 1][2], row[K - 1][3]);
             } else {
 #pragma unroll
-                for (int c = 0; c < OD; ++c) o[c] = src[c];
+                for (int c = 0; c < OD; ++c) o[c] = row[K - 1][c];
             }
         }
     });
@@ -652,27 +698,40 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         const float sr2 = sr * sr, cr2 = cr * cr;
         __syncthreads();  // LDS prey block visible (single-wave workgroup: waitcnt + s_barrier)
         uint32_t nsen_lo = sen_lo, nsen_hi = sen_hi, ncap_lo = cap_lo, ncap_hi = cap_hi;
+        // The prey block is scanned four at a time (LDS reads in flight together).  scan(lo, hi, f)
+        // calls f(i, prey_x, prey_y, d2) for i in [lo, hi).
+        auto scan = [&](int lo, int hi, auto &&f) {
+            for (int i0 = lo; i0 < hi; i0 += 4) {
+                float2 pl[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i = (i0 + t) < hi ? (i0 + t) : (hi - 1);
+                    pl[t] = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * i]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float dx = x - pl[t].x, dy = y - pl[t].y;
+                    f(i0 + t, (i0 + t) < hi, pl[t].x, pl[t].y, dx * dx + dy * dy);
+                }
+            }
+        };
         if constexpr (!OBS_ONLY) {  // a11 _update_tracking_and_locations (PredatorCapturePrey.py:72-95)
             uint32_t s_lo = 0, s_hi = 0, c_lo = 0, c_hi = 0;  // prey this agent senses / could capture
             const bool acts = lane_ok & (act == 4);
-            for (int i = 0; i < P; ++i) {
-                const float2 pl = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * i]);
-                const float dx = x - pl.x, dy = y - pl.y;
-                const float d2 = dx * dx + dy * dy;
-                const uint32_t sb = (lane_ok & (d2 <= sr2)) ? 1u : 0u, cb = (acts & (d2 <= cr2)) ? 1u : 0u;
-                if (i < 32) {
-                    s_lo |= sb << i;
-                    c_lo |= cb << i;
-                } else {
-                    s_hi |= sb << (i - 32);
-                    c_hi |= cb << (i - 32);
-                }
-            }
+            const int P32 = P < 32 ? P : 32;
+            scan(0, P32, [&](int i, bool in, float, float, float d2) {
+                s_lo |= ((in & lane_ok & (d2 <= sr2)) ? 1u : 0u) << (i & 31);
+                c_lo |= ((in & acts & (d2 <= cr2)) ? 1u : 0u) << (i & 31);
+            });
             s_lo = group_or<GW>(s_lo);
             c_lo = group_or<GW>(c_lo);
             nsen_lo = sen_lo | (s_lo & ~cap_lo);          // sensed: any agent in range, prey not yet captured
             ncap_lo = cap_lo | (nsen_lo & c_lo & ~cap_lo);  // captured: sensed and a 'no_action' agent in range
             if (P > 32) {
+                scan(32, P, [&](int i, bool in, float, float, float d2) {
+                    s_hi |= ((in & lane_ok & (d2 <= sr2)) ? 1u : 0u) << ((i - 32) & 31);
+                    c_hi |= ((in & acts & (d2 <= cr2)) ? 1u : 0u) << ((i - 32) & 31);
+                });
                 s_hi = group_or<GW>(s_hi);
                 c_hi = group_or<GW>(c_hi);
                 nsen_hi = sen_hi | (s_hi & ~cap_hi);
@@ -689,15 +748,18 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         }
         // a13 own observation: nearest uncaptured prey within the agent's own sensing radius
         float closest = -1.0f, qx = -5.0f, qy = -5.0f;
-        for (int i = 0; i < P; ++i) {
-            const float2 pl = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * i]);
-            const float dx = x - pl.x, dy = y - pl.y;
-            const float d2 = dx * dx + dy * dy;
-            const bool cap = ((i < 32 ? ncap_lo >> i : ncap_hi >> (i - 32)) & 1u) != 0;
-            const bool take = !cap & (d2 <= sr2) & ((d2 < closest) | (closest == -1.0f));
-            qx = take ? pl.x : qx;
-            qy = take ? pl.y : qy;
-            closest = take ? d2 : closest;
+        {
+            auto nearest = [&](uint32_t capmask, int base) {
+                return [&, capmask, base](int i, bool in, float px, float py, float d2) {
+                    const bool cap = ((capmask >> ((i - base) & 31)) & 1u) != 0;
+                    const bool take = in & !cap & (d2 <= sr2) & ((d2 < closest) | (closest == -1.0f));
+                    qx = take ? px : qx;
+                    qy = take ? py : qy;
+                    closest = take ? d2 : closest;
+                };
+            };
+            scan(0, P < 32 ? P : 32, nearest(ncap_lo, 0));
+            if (P > 32) scan(32, P, nearest(ncap_hi, 32));
         }
         const int od = p.capability_aware ? 6 : 4;
         lds.own[lane][0] = x;

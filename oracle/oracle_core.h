@@ -84,6 +84,7 @@ static inline float FN(wrap)(float t) {
 #define SINCOS(t, s, c) FN(sincos)((t), (s), (c))
 #define ATAN2(y, x) FN(atan2)((y), (x))
 #define SQRT(v) __builtin_sqrtf(v)
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 /* float spec: range tests and nearest-neighbour / nearest-prey ordering compare SQUARED distances
  * (d2 <= r*r, d2_a < d2_b): the same decisions as the reference's norm() <= r except within an ulp
  * of the threshold, and no sqrt in the scenario epilogue */
@@ -94,6 +95,7 @@ static inline float FN(wrap)(float t) {
 #define ATAN2(y, x) atan2((y), (x))
 #define WRAP(t) atan2(sin(t), cos(t))
 #define SQRT(v) sqrt(v)
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define DIST(d2) sqrt(d2)
 #define RADIUS(r) (r)
 #endif
@@ -128,14 +130,23 @@ static inline REAL FN(clampv)(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (
 
 /* a6: barrier certificate as an exact projection (Hildreth sweeps in XOR-factorisation order) */
 static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REAL *xiy, REAL *ux, REAL *uy) {
+    /* min ||u - uhat||^2  s.t.  e_ij.(u_j - u_i) <= beta_ij  (rps' rows halved; e_ij = xi_i - xi_j,
+     * beta = gamma h^3 / 2), solved as the exact projection by Hildreth's dual coordinate ascent:
+     * multipliers mu_ij >= 0, u = uhat + sum_ij mu_ij (e_ij at i, -e_ij at j).  Pairs are visited in
+     * the XOR 1-factorisation order (k = 1..GW-1, pairs (a, a^k)) that the HIP kernel runs
+     * pair-parallel.  One pair update, with f = e/n2, bp = beta/n2, n2 = 2|e|^2:
+     *     mn = max(0, mu - bp + f.(u_j - u_i));  delta = mn - mu;  u_i += delta e;  u_j -= delta e.
+     * Coupled constraints converge geometrically (ratio <= 1/4 per sweep for two pairs sharing a
+     * robot), so after sweeps 3, 7, 11, ... the multipliers are Aitken-extrapolated
+     * (mu - d2^2/(d2 - d1) where the last two changes d1, d2 shrink with a common sign) and u is
+     * rebuilt from them: a restart from a better point of the same convergent iteration. */
     int gw = 2;
     while (gw < N) gw *= 2;
     REAL r2 = R(p->safety_radius) * R(p->safety_radius);
-    REAL ex[ORC_MAXN][ORC_MAXN], ey[ORC_MAXN][ORC_MAXN], beta[ORC_MAXN][ORC_MAXN], n2[ORC_MAXN][ORC_MAXN],
-        mu[ORC_MAXN][ORC_MAXN];
-#if ORC_IS_F32
-    REAL rn2[ORC_MAXN][ORC_MAXN];
-#endif
+    REAL ex[ORC_MAXN][ORC_MAXN], ey[ORC_MAXN][ORC_MAXN], fx[ORC_MAXN][ORC_MAXN], fy[ORC_MAXN][ORC_MAXN],
+        bp[ORC_MAXN][ORC_MAXN], emax[ORC_MAXN][ORC_MAXN], mu[ORC_MAXN][ORC_MAXN], muA[ORC_MAXN][ORC_MAXN],
+        muB[ORC_MAXN][ORC_MAXN];
+    int valid[ORC_MAXN][ORC_MAXN];
     for (int i = 0; i < N; ++i)
         for (int j = i + 1; j < N; ++j) {
             REAL dx = xix[i] - xix[j], dy = xiy[i] - xiy[j];
@@ -143,16 +154,20 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
             REAL h = ee - r2;
             REAL gain = (h >= R(0) || !p->barrier_has_unsafe_gain) ? R(p->barrier_gain) : R(p->unsafe_barrier_gain);
             REAL b = gain * ((h * h) * h);
+            REAL n2 = R(2) * ee;
+            valid[i][j] = n2 > R(0);
+            REAL rn2 = valid[i][j] ? R(1) / n2 : R(0); /* one division per pair per QP */
+            REAL ax = dx < R(0) ? -dx : dx, ay = dy < R(0) ? -dy : dy;
             ex[i][j] = dx;
             ey[i][j] = dy;
-            beta[i][j] = R(0.5) * b;
-            n2[i][j] = R(2) * ee;
-#if ORC_IS_F32
-            if (n2[i][j] > R(0)) rn2[i][j] = R(1) / n2[i][j]; /* float spec: one division per pair per QP */
-#endif
-            mu[i][j] = R(0);
+            fx[i][j] = dx * rn2;
+            fy[i][j] = dy * rn2;
+            bp[i][j] = (R(0.5) * b) * rn2;
+            emax[i][j] = ax > ay ? ax : ay;
+            mu[i][j] = muA[i][j] = muB[i][j] = R(0);
         }
     /* "Threshold control inputs before QP" */
+    REAL uhx[ORC_MAXN], uhy[ORC_MAXN];
     for (int a = 0; a < N; ++a) {
         REAL nrm = SQRT(ux[a] * ux[a] + uy[a] * uy[a]);
         if (nrm > R(p->barrier_magnitude_limit)) {
@@ -160,36 +175,36 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
             ux[a] = ux[a] * sc;
             uy[a] = uy[a] * sc;
         }
+        uhx[a] = ux[a];
+        uhy[a] = uy[a];
     }
     int sweeps = 0;
     for (;;) {
         REAL maxchg = R(0);
+        for (int i = 0; i < N; ++i)
+            for (int j = i + 1; j < N; ++j) {
+                muA[i][j] = muB[i][j];
+                muB[i][j] = mu[i][j];
+            }
         for (int k = 1; k < gw; ++k)
             for (int i = 0; i < N; ++i) {
                 int j = i ^ k;
-                if (!(i < j && j < N)) continue;
-                if (!(n2[i][j] > R(0))) continue;
-                REAL r = ex[i][j] * (ux[j] - ux[i]) + ey[i][j] * (uy[j] - uy[i]) - beta[i][j];
-#if ORC_IS_F32
-                REAL d = r * rn2[i][j];
-#else
-                REAL d = r / n2[i][j];
-#endif
-                REAL mn = mu[i][j] + d;
+                if (!(i < j && j < N) || !valid[i][j]) continue;
+                REAL c0 = mu[i][j] - bp[i][j];
+                REAL t = FMA(fy[i][j], uy[j] - uy[i], c0);
+                REAL mn = FMA(fx[i][j], ux[j] - ux[i], t);
                 if (!(mn > R(0))) mn = R(0);
                 REAL delta = mn - mu[i][j];
                 mu[i][j] = mn;
-                REAL cx = delta * ex[i][j], cy = delta * ey[i][j];
-                ux[i] = ux[i] + cx;
-                uy[i] = uy[i] + cy;
-                ux[j] = ux[j] - cx;
-                uy[j] = uy[j] - cy;
-                REAL acx = cx < R(0) ? -cx : cx, acy = cy < R(0) ? -cy : cy;
-                if (acx > maxchg) maxchg = acx;
-                if (acy > maxchg) maxchg = acy;
+                ux[i] = FMA(delta, ex[i][j], ux[i]);
+                uy[i] = FMA(delta, ey[i][j], uy[i]);
+                ux[j] = FMA(-delta, ex[i][j], ux[j]);
+                uy[j] = FMA(-delta, ey[i][j], uy[j]);
+                REAL chg = (delta < R(0) ? -delta : delta) * emax[i][j]; /* = max(|delta ex|, |delta ey|) */
+                if (chg > maxchg) maxchg = chg;
             }
         ++sweeps;
-        /* converged when the largest component change of the sweep is below QP_RTOL relative to
+        /* converged when the largest component change of the sweep is below qp_rtol relative to
          * max(|u|_inf, magnitude_limit) */
         REAL umax = R(p->barrier_magnitude_limit);
         for (int a = 0; a < N; ++a) {
@@ -198,6 +213,33 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
             if (ay > umax) umax = ay;
         }
         if (!(maxchg > R(p->qp_rtol) * umax) || sweeps >= p->qp_max_sweeps) break;
+        if ((sweeps & 3) == 3) { /* Aitken restart */
+            for (int i = 0; i < N; ++i)
+                for (int j = i + 1; j < N; ++j) {
+                    if (!valid[i][j]) continue;
+                    REAL d1 = muB[i][j] - muA[i][j], d2 = mu[i][j] - muB[i][j];
+                    REAL a1 = d1 < R(0) ? -d1 : d1, a2 = d2 < R(0) ? -d2 : d2;
+                    if (d1 != R(0) && d2 != R(0) && ((d1 > R(0)) == (d2 > R(0))) && a2 < R(0.97) * a1) {
+                        REAL m = mu[i][j] - (d2 * d2) / (d2 - d1);
+                        if (!(m > R(0))) m = R(0);
+                        mu[i][j] = m;
+                    }
+                }
+            for (int a = 0; a < N; ++a) { /* u = uhat + sum over partners, in round order */
+                REAL sx = uhx[a], sy = uhy[a];
+                for (int k = 1; k < gw; ++k) {
+                    int q = a ^ k;
+                    if (q >= N) continue;
+                    int lo = a < q ? a : q, hi = a < q ? q : a;
+                    if (!valid[lo][hi]) continue;
+                    REAL sgn_ex = a < q ? ex[lo][hi] : -ex[lo][hi], sgn_ey = a < q ? ey[lo][hi] : -ey[lo][hi];
+                    sx = FMA(mu[lo][hi], sgn_ex, sx);
+                    sy = FMA(mu[lo][hi], sgn_ey, sy);
+                }
+                ux[a] = sx;
+                uy[a] = sy;
+            }
+        }
     }
     return sweeps;
 }
@@ -686,6 +728,7 @@ int FN(orc_controller)(const orc_params *p, const REAL *poses /*3xN*/, const REA
 #undef ATAN2
 #undef WRAP
 #undef SQRT
+#undef FMA
 #undef DIST
 #undef RADIUS
 #undef R

@@ -40,36 +40,60 @@ def pair_order(N):
 def solve_pair_qp(uhat, x, beta, rtol=QP_RTOL_F64, max_sweeps=QP_MAX_SWEEPS_F64, magnitude_limit=0.2):
     """Projection of uhat (2xN) onto { u : e_ij.(u_j - u_i) <= beta_ij for all i<j },
     e_ij = x_i - x_j.  (Upstream's row  -2e.u_i + 2e.u_j <= b  divided by two; beta = b/2.)
-    beta is a dict {(i,j): value}.  Returns (u, sweeps)."""
+    beta is a dict {(i,j): value}.  Returns (u, sweeps).
+
+    Hildreth sweeps in the XOR-factorisation pair order, with an Aitken restart of the
+    multipliers after sweeps 3, 7, 11, ... (see oracle/oracle_core.h barrier_qp, the same
+    algorithm in C)."""
     N = uhat.shape[1]
+    gw = group_width(N)
     u = uhat.copy()
     order = pair_order(N)
+    e = {(i, j): (x[0, i] - x[0, j], x[1, i] - x[1, j]) for (i, j) in order}
+    n2 = {pr: 2.0 * (e[pr][0] * e[pr][0] + e[pr][1] * e[pr][1]) for pr in order}
+    order = [pr for pr in order if n2[pr] > 0.0]
+    rn2 = {pr: 1.0 / n2[pr] for pr in order}
     mu = {pr: 0.0 for pr in order}
+    muA = dict(mu)
+    muB = dict(mu)
     sweeps = 0
     while True:
         maxchg = 0.0
+        muA, muB = muB, dict(mu)
         for (i, j) in order:
-            ex = x[0, i] - x[0, j]
-            ey = x[1, i] - x[1, j]
-            n2 = 2.0 * (ex * ex + ey * ey)
-            if not n2 > 0.0:
-                continue
-            r = ex * (u[0, j] - u[0, i]) + ey * (u[1, j] - u[1, i]) - beta[(i, j)]
-            d = r / n2
-            mu_new = max(0.0, mu[(i, j)] + d)
-            delta = mu_new - mu[(i, j)]
-            mu[(i, j)] = mu_new
-            cx = delta * ex
-            cy = delta * ey
-            u[0, i] = u[0, i] + cx
-            u[1, i] = u[1, i] + cy
-            u[0, j] = u[0, j] - cx
-            u[1, j] = u[1, j] - cy
-            maxchg = max(maxchg, abs(cx), abs(cy))
+            ex, ey = e[(i, j)]
+            r = rn2[(i, j)]
+            mn = (mu[(i, j)] - (0.5 * (2.0 * beta[(i, j)])) * r) + ((ey * r) * (u[1, j] - u[1, i])) \
+                + ((ex * r) * (u[0, j] - u[0, i]))
+            mn = max(0.0, mn)
+            delta = mn - mu[(i, j)]
+            mu[(i, j)] = mn
+            u[0, i] += delta * ex
+            u[1, i] += delta * ey
+            u[0, j] -= delta * ex
+            u[1, j] -= delta * ey
+            maxchg = max(maxchg, abs(delta) * max(abs(ex), abs(ey)))
         sweeps += 1
         umax = max(magnitude_limit, float(np.abs(u).max()))
         if maxchg <= rtol * umax or sweeps >= max_sweeps:
             break
+        if (sweeps & 3) == 3:
+            for pr in order:
+                d1, d2 = muB[pr] - muA[pr], mu[pr] - muB[pr]
+                if d1 != 0.0 and d2 != 0.0 and ((d1 > 0) == (d2 > 0)) and abs(d2) < 0.97 * abs(d1):
+                    mu[pr] = max(0.0, mu[pr] - (d2 * d2) / (d2 - d1))
+            u = uhat.copy()
+            for a in range(N):
+                for k in range(1, gw):
+                    q = a ^ k
+                    if q >= N:
+                        continue
+                    pr = (min(a, q), max(a, q))
+                    if pr not in mu:
+                        continue
+                    s = 1.0 if a < q else -1.0
+                    u[0, a] += mu[pr] * (s * e[pr][0])
+                    u[1, a] += mu[pr] * (s * e[pr][1])
     return u, sweeps
 
 
