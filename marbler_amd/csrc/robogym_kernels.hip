@@ -32,7 +32,10 @@
 namespace rg {
 
 constexpr int WAVE = 64;
-constexpr int CHUNK = 4;        // sub-steps validated together (ILP across independent test chains)
+#ifndef RG_CHUNK
+#define RG_CHUNK 4
+#endif
+constexpr int CHUNK = RG_CHUNK;  // sub-steps validated together (ILP across independent test chains); 8 measured no faster
 constexpr int MAX_DRAWS = 128;  // u32 draws per reset: 4 + 2N + P <= 4 + 32 + 64, rounded up to blocks
 
 // ------------------------------------------------------------------ lane exchange (DPP)
