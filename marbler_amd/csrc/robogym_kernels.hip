@@ -90,6 +90,18 @@ __device__ __forceinline__ float group_max(float v) {
     if constexpr (GW >= 16) v = fmaxf(v, xor_lane<15>(v));
     return v;
 }
+// the same for NON-NEGATIVE floats, on their bit patterns (order-preserving; lets the DPP permute
+// fuse into v_max_u32 and needs no NaN canonicalisation)
+template <int GW>
+__device__ __forceinline__ float group_max_nonneg(float f) {
+    uint32_t v = __builtin_bit_cast(uint32_t, f);
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, static_cast<uint32_t>(xor_lane_i<1>(static_cast<int>(v))));
+    v = mx(v, static_cast<uint32_t>(xor_lane_i<2>(static_cast<int>(v))));
+    if constexpr (GW >= 8) v = mx(v, static_cast<uint32_t>(xor_lane_i<7>(static_cast<int>(v))));
+    if constexpr (GW >= 16) v = mx(v, static_cast<uint32_t>(xor_lane_i<15>(static_cast<int>(v))));
+    return __builtin_bit_cast(float, v);
+}
 template <int GW>
 __device__ __forceinline__ uint32_t group_or(uint32_t v) {
     v |= static_cast<uint32_t>(xor_lane_i<1>(static_cast<int>(v)));
@@ -190,14 +202,15 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     // is active.
     bool active = upd;
     int sweeps = 0, my_sweeps = 0;
-    while (__any(active)) {
+    // one sweep over the GW-1 rounds + the convergence test; PHASE = sweep number mod 4 selects the
+    // Aitken bookkeeping (record mu after sweeps 1 and 2 of each block of four, restart after the 3rd)
+    auto sweep = [&](auto PH) {
+        constexpr int PHASE = decltype(PH)::value;
         ++sweeps;
         if (active) {
             float chg = 0.0f;
             static_for<1, GW>([&](auto KK) {
                 constexpr int K = decltype(KK)::value;
-                muA[K - 1] = muB[K - 1];
-                muB[K - 1] = mu[K - 1];
                 const float pux = xor_lane<K>(ux), puy = xor_lane<K>(uy);
                 const float c0 = mu[K - 1] - bp[K - 1];
                 const float t = __builtin_fmaf(fy[K - 1], puy - uy, c0);
@@ -208,29 +221,42 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
                 ux = __builtin_fmaf(delta, ex[K - 1], ux);
                 uy = __builtin_fmaf(delta, ey[K - 1], uy);
                 chg = fmaxf(chg, __builtin_fabsf(delta) * emax[K - 1]);
+                if constexpr (PHASE == 1) muA[K - 1] = mn;
+                if constexpr (PHASE == 2) muB[K - 1] = mn;
             });
             my_sweeps = sweeps;
             const float um = lane_ok ? fmaxf(__builtin_fabsf(ux), __builtin_fabsf(uy)) : 0.0f;
-            const float gchg = group_max<GW>(chg);
-            const float gum = fmaxf(k.bml, group_max<GW>(um));
+            const float gchg = group_max_nonneg<GW>(chg);
+            const float gum = fmaxf(k.bml, group_max_nonneg<GW>(um));
             active = (gchg > qp_rtol * gum) & (sweeps < qp_cap);
-            if (active & ((sweeps & 3) == 3)) {  // Aitken restart of the multipliers, u rebuilt from them
-                float sx = uhx, sy = uhy;
-                static_for<1, GW>([&](auto KK) {
-                    constexpr int K = decltype(KK)::value;
-                    const float d1 = muB[K - 1] - muA[K - 1], d2 = mu[K - 1] - muB[K - 1];
-                    const bool geo = (d1 != 0.0f) & (d2 != 0.0f) & ((d1 > 0.0f) == (d2 > 0.0f)) &
-                                     (__builtin_fabsf(d2) < 0.97f * __builtin_fabsf(d1)) & (emax[K - 1] > 0.0f);
-                    float m = mu[K - 1] - (d2 * d2) / (d2 - d1);
-                    m = (m > 0.0f) ? m : 0.0f;
-                    mu[K - 1] = geo ? m : mu[K - 1];
-                    sx = __builtin_fmaf(mu[K - 1], ex[K - 1], sx);
-                    sy = __builtin_fmaf(mu[K - 1], ey[K - 1], sy);
-                });
-                ux = sx;
-                uy = sy;
+            if constexpr (PHASE == 3) {
+                if (active) {  // Aitken restart of the multipliers, u rebuilt from them
+                    float sx = uhx, sy = uhy;
+                    static_for<1, GW>([&](auto KK) {
+                        constexpr int K = decltype(KK)::value;
+                        const float d1 = muB[K - 1] - muA[K - 1], d2 = mu[K - 1] - muB[K - 1];
+                        const bool geo = (d1 != 0.0f) & (d2 != 0.0f) & ((d1 > 0.0f) == (d2 > 0.0f)) &
+                                         (__builtin_fabsf(d2) < 0.97f * __builtin_fabsf(d1)) & (emax[K - 1] > 0.0f);
+                        float m = mu[K - 1] - (d2 * d2) / (d2 - d1);
+                        m = (m > 0.0f) ? m : 0.0f;
+                        mu[K - 1] = geo ? m : mu[K - 1];
+                        sx = __builtin_fmaf(mu[K - 1], ex[K - 1], sx);
+                        sy = __builtin_fmaf(mu[K - 1], ey[K - 1], sy);
+                    });
+                    ux = sx;
+                    uy = sy;
+                }
             }
         }
+    };
+    while (__any(active)) {
+        sweep(std::integral_constant<int, 1>{});
+        if (!__any(active)) break;
+        sweep(std::integral_constant<int, 2>{});
+        if (!__any(active)) break;
+        sweep(std::integral_constant<int, 3>{});
+        if (!__any(active)) break;
+        sweep(std::integral_constant<int, 0>{});
     }
     // a7 si_to_uni_dyn, a8 set_velocities
     float vv = c * ux + s * uy;
