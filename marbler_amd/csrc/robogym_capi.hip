@@ -14,6 +14,7 @@
 
 struct rg_handle {
     rg_scenario_params params;
+    rg::Consts consts;
     rg_state state;
     int32_t num_envs;
     int64_t env_offset;
@@ -92,6 +93,7 @@ rg_handle *rg_create(const rg_scenario_params *params, int32_t num_envs, int64_t
         return nullptr;
     }
     h->params = *params;
+    h->consts = rg::make_consts(*params);
     memset(&h->state, 0, sizeof(h->state));
     h->num_envs = num_envs;
     h->env_offset = env_offset;
@@ -136,6 +138,7 @@ static int fill_args(rg_handle *h, rg::KernelArgs &a) {
     if (!h->bound) return fail(-22, "rg_bind_state has not been called");
     memset(&a, 0, sizeof(a));
     a.p = h->params;
+    a.k = h->consts;
     a.st = h->state;
     a.E = h->num_envs;
     a.env_offset = h->env_offset;

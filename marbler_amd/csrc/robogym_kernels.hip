@@ -118,32 +118,6 @@ __device__ __forceinline__ bool group_any(bool pred, int gbase) {
     return ((m >> gbase) & GM) != 0ull;
 }
 
-struct Consts {  // derived scalars, computed in binary32 in the same form as the oracle
-    float dt, pd, inv_pd, r2, wlim, vmax, wmax, pvl, bml;
-    float xmin, xmax, ymin, ymax, coll_off, coll_lim2;
-};
-__device__ __forceinline__ Consts make_consts(const rg_scenario_params &p) {
-    Consts k;
-    k.dt = p.time_step;
-    k.pd = p.projection_distance;
-    k.inv_pd = 1.0f / p.projection_distance;
-    k.r2 = p.safety_radius * p.safety_radius;
-    k.wlim = p.angular_velocity_limit;
-    k.vmax = p.max_linear_velocity;
-    k.wmax = 2.0f * (p.wheel_radius / p.robot_diameter) * (p.max_linear_velocity / p.wheel_radius);
-    k.pvl = p.position_velocity_limit;
-    k.bml = p.barrier_magnitude_limit;
-    k.xmin = p.bound_x0;
-    k.ymin = p.bound_y0;
-    k.xmax = p.bound_x0 + p.bound_w;
-    k.ymax = p.bound_y0 + p.bound_h;
-    const bool off = p.collision_variant == RG_COLLISION_OFFSET;
-    k.coll_off = off ? p.collision_offset : 0.0f;
-    const float lim = off ? p.collision_diameter : p.robot_diameter;
-    k.coll_lim2 = lim * lim;
-    return k;
-}
-
 // ------------------------------------------------------------------ controller (a3..a8)
 // utilities/controller.py:20-24 over the restated rps closures,
 // followed by Robotarium.set_velocities' clipping.  Called in wave-uniform control flow.
@@ -280,8 +254,8 @@ struct alignas(16) Lds {
     float ax[WAVE], ay[WAVE];                // MaterialTransport sequential replay / reward sum
     int aload[WAVE];
     uint32_t draws[WAVE / GW][MAX_DRAWS];    // reset: Philox output
-    uint8_t perm[WAVE / GW][64];             // reset: Fisher-Yates permutation of the grid cells
-    uint8_t sel[WAVE / GW][64];              // reset: chosen cells
+    uint8_t perm[WAVE / GW][2][64];          // reset: Fisher-Yates permutations of the grid cells (agents, prey)
+    uint8_t sel[WAVE / GW][2][64];           // reset: chosen cells
 };
 
 // ------------------------------------------------------------------ reset sampler (a17)
@@ -304,22 +278,30 @@ __device__ __forceinline__ int normal_int(uint32_t r1, uint32_t r2, float mean, 
     return static_cast<int>(mean + stdv * (rad * cs));
 }
 
+// Partial Fisher-Yates over the grid cells.  The agents' draw and (PredatorCapturePrey) the prey's
+// draw are independent chains, so they run side by side on lanes 0 and 1 of the group, each on its
+// own permutation array (same instructions, different data).
 template <int GW>
-__device__ __forceinline__ void fisher_yates(Lds<GW> &lds, int g, int ag, bool do_reset, const rg_grid &grid,
-                                             int count, int first_draw) {
-    const int C = grid.nx * grid.ny;
-    if (do_reset)
-        for (int i = ag; i < C; i += GW) lds.perm[g][i] = static_cast<uint8_t>(i);
+__device__ __forceinline__ void fisher_yates2(Lds<GW> &lds, int g, int ag, bool do_reset, const rg_grid &grid_a,
+                                              int count_a, int first_a, const rg_grid &grid_b, int count_b,
+                                              int first_b) {
+    const int Ca = grid_a.nx * grid_a.ny, Cb = count_b > 0 ? grid_b.nx * grid_b.ny : 0;
+    if (do_reset) {
+        for (int i = ag; i < Ca; i += GW) lds.perm[g][0][i] = static_cast<uint8_t>(i);
+        for (int i = ag; i < Cb; i += GW) lds.perm[g][1][i] = static_cast<uint8_t>(i);
+    }
     __syncthreads();
-    if (do_reset && ag == 0) {
+    if (do_reset && ag < 2) {
+        const int which = ag;
+        const int C = which ? Cb : Ca, count = which ? count_b : count_a, first = which ? first_b : first_a;
         for (int i = 0; i < count; ++i) {
-            const uint32_t r = lds.draws[g][first_draw + i];
+            const uint32_t r = lds.draws[g][first + i];
             const int j = i + static_cast<int>((static_cast<uint64_t>(r) * static_cast<uint32_t>(C - i)) >> 32);
-            const uint8_t t = lds.perm[g][i];
-            const uint8_t pj = lds.perm[g][j];
-            lds.perm[g][j] = t;
-            lds.perm[g][i] = pj;
-            lds.sel[g][i] = pj;
+            const uint8_t t = lds.perm[g][which][i];
+            const uint8_t pj = lds.perm[g][which][j];
+            lds.perm[g][which][j] = t;
+            lds.perm[g][which][i] = pj;
+            lds.sel[g][which][i] = pj;
         }
     }
     __syncthreads();
@@ -355,10 +337,10 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
             lds.draws[g][4 * b + 3] = blk[3];
         }
     }
-    fisher_yates<GW>(lds, g, ag, do_reset, p.agent_grid, N, ZD);  // syncs inside: draws + perm visible
+    fisher_yates2<GW>(lds, g, ag, do_reset, p.agent_grid, N, ZD, p.prey_grid, P, ZD + 2 * N);  // syncs inside
     if (do_reset && ag < N) {
         float x, y;
-        cell_xy(p.agent_grid, lds.sel[g][ag], x, y);
+        cell_xy(p.agent_grid, lds.sel[g][0][ag], x, y);
         const float th = uniform01(lds.draws[g][ZD + N + ag]) * 6.283185482025146484375f - 3.1415927410125732421875f;
         float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
         X[ag] = x;
@@ -378,11 +360,10 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
         }
     }
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-        fisher_yates<GW>(lds, g, ag, do_reset, p.prey_grid, P, ZD + 2 * N);
         if (do_reset) {
             for (int i = ag; i < P; i += GW) {
                 float x, y;
-                cell_xy(p.prey_grid, lds.sel[g][i], x, y);
+                cell_xy(p.prey_grid, lds.sel[g][1][i], x, y);
                 float *pl = a.st.prey_loc + (static_cast<size_t>(e) * P + i) * 2;
                 pl[0] = x;
                 pl[1] = y;
@@ -482,7 +463,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
 #endif
     __shared__ Lds<GW> lds;
     const rg_scenario_params &p = a.p;
-    const Consts k = make_consts(p);
+    const Consts &k = a.k;
     const int N = p.n_agents;
     const int lane = threadIdx.x;
     const int ag = lane & (GW - 1);
@@ -531,10 +512,21 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     uint8_t loaded = 0;                                      // Warehouse
     int load = 0, zone0 = 0, zone1 = 0;                      // MaterialTransport
     int msg[4] = {0, 0, 0, 0};
+    // PCP: the env's prey block is fetched into registers now (up to PRE floats per lane, i.e.
+    // P <= PRE*GW/2 prey) and put into LDS only when the epilogue needs it, so the load latency
+    // hides behind the sub-step loop; larger P take the direct copy below.
+    constexpr int PRE = 4;
+    float pre[PRE] = {0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
         if (env_ok) {
-            for (int i = ag; i < 2 * P; i += GW) lds.prey[g][i] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + i];
+            if (2 * P <= PRE * GW) {
+#pragma unroll
+                for (int t = 0; t < PRE; ++t)
+                    if (ag + t * GW < 2 * P) pre[t] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + ag + t * GW];
+            } else {
+                for (int i = ag; i < 2 * P; i += GW) lds.prey[g][i] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + i];
+            }
             for (int i = ag; i < P; i += GW) {
                 const uint32_t sb = a.st.prey_sensed[static_cast<size_t>(e) * P + i] != 0;
                 const uint32_t cb = a.st.prey_captured[static_cast<size_t>(e) * P + i] != 0;
@@ -600,9 +592,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         // collision the float test would flag.  Absent lanes / finished envs sit on far-apart ghost
         // points.  CHUNK sub-steps are advanced and tested together: their test chains are
         // independent, which is the only ILP a single wavefront has here.
-        const float lim = __builtin_sqrtf(k.coll_lim2);
-        const float lq = __builtin_fmaf(lim, 8191.75f, 4.0f);
-        const int thr_q = static_cast<int>(lq * lq) + 1;
+        const int thr_q = k.thr_q;
         const int ghost_q = (32767 & 0xFFFF) | (((-28000 + 3500 * ag) & 0xFFFF) << 16);  // >= 0.43 m apart, > 2 m off
         float v = 0.0f, w = 0.0f, s = 0.0f, c = 1.0f;
         float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
@@ -725,6 +715,11 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
         const float sr2 = sr * sr, cr2 = cr * cr;
+        if (2 * P <= PRE * GW) {
+#pragma unroll
+            for (int t = 0; t < PRE; ++t)
+                if (ag + t * GW < 2 * P) lds.prey[g][ag + t * GW] = pre[t];
+        }
         __syncthreads();  // LDS prey block visible (single-wave workgroup: waitcnt + s_barrier)
         uint32_t nsen_lo = sen_lo, nsen_hi = sen_hi, ncap_lo = cap_lo, ncap_hi = cap_hi;
         // The prey block is scanned four at a time (LDS reads in flight together).  scan(lo, hi, f)
