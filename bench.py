@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scenario", default="PredatorCapturePrey")
+    ap.add_argument("--dist-backend", default=None, help="nccl (default, = RCCL) | gloo (CPU rehearsal of the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (a 1-GPU box); never for a measured run")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +86,9 @@ def main():
     from marbler_amd import VecRobotariumEnv, make_params, load_config
     from marbler_amd import dist as rgdist
 
-    rank, world, local = rgdist.init_from_env()
+    rank, world, local = rgdist.init_from_env(backend=args.dist_backend)
+    if args.share_gpu:
+        local = 0
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -133,7 +138,7 @@ def main():
     assert rc == 0
     gpu_ms_total = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=rgdist.collective_device(dev), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -26,8 +26,18 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def collective_device(device):
+    """Where tensors handed to a collective must live: the GPU for nccl (RCCL), the CPU for gloo."""
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return torch.device(device)
 
 
 def shard(total_envs, rank, world):
@@ -43,7 +53,8 @@ def broadcast_params(params, src=0, device=None):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return params
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = collective_device(device)
     if dist.get_rank() == src:
         buf = torch.frombuffer(bytearray(params_to_bytes(params)), dtype=torch.uint8).to(device)
     else:
@@ -61,7 +72,9 @@ def gather_episode_stats(done_return_sum, done_count, done_steps_sum, dst=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return done_return_sum, done_count, done_steps_sum
     world = dist.get_world_size()
-    n = torch.tensor([done_return_sum.numel()], device=done_return_sum.device)
+    cdev = collective_device(done_return_sum.device)
+    done_return_sum, done_count, done_steps_sum = (t.to(cdev) for t in (done_return_sum, done_count, done_steps_sum))
+    n = torch.tensor([done_return_sum.numel()], device=cdev)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     m = int(max(s.item() for s in sizes))
