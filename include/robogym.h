@@ -29,7 +29,15 @@ extern "C" {
 #define RG_MAX_PREY 64
 
 /* scenarios/<S>/ : wrapper.py:12-16 env_dict */
-enum { RG_SCN_PREDATOR_CAPTURE_PREY = 0, RG_SCN_WAREHOUSE = 1, RG_SCN_MATERIAL_TRANSPORT = 2 };
+enum {
+    RG_SCN_PREDATOR_CAPTURE_PREY = 0,
+    RG_SCN_WAREHOUSE = 1,
+    RG_SCN_MATERIAL_TRANSPORT = 2,
+    RG_SCN_SIMPLE = 3,
+    RG_SCN_ARCTIC_TRANSPORT = 4
+};
+#define RG_ARCTIC_ROWS 8
+#define RG_ARCTIC_COLS 12
 /* rps _validate collision test */
 enum { RG_COLLISION_CENTER = 0, RG_COLLISION_OFFSET = 1 };
 /* info['message'] of the reference (utilities/roboEnv.py:82-94) as a code */
@@ -79,6 +87,9 @@ typedef struct rg_scenario_params {
     float time_penalty, sense_reward, capture_reward, violation_reward;
     float load_reward, unload_reward, goal_width;
     float unload_multiplier, load_multiplier, end_goal_width, zone1_radius;
+    float reward_scaler;                          /* Simple (simple.py:219-222) */
+    float arctic_normal_step, arctic_slow_step, arctic_fast_step; /* ArcticTransport agent.py:89-113 */
+    float not_reached_penalty, dist_multiplier;   /* ArcticTransport.py:125-134 */
     /* reset (misc.py:49-63, scenario reset()) */
     rg_grid agent_grid, prey_grid;
     int32_t keep_theta;              /* Warehouse keeps the sampled heading, misc.py:58,62 zero it */
@@ -95,13 +106,17 @@ typedef struct rg_state {
                                added to dist_travelled (roboEnv.py:55-59 lags one iteration) */
     int32_t *episode_steps; /* [E] */
     int32_t *reset_count;   /* [E] episodes started so far (RNG stream position) */
-    float *prey_loc;        /* [E][P][2]   PredatorCapturePrey */
+    float *prey_loc;        /* [E][P][2]   PredatorCapturePrey; Simple keeps its goal here (P = 1) */
     uint8_t *prey_sensed;   /* [E][P] */
     uint8_t *prey_captured; /* [E][P] */
     uint8_t *loaded;        /* [E][N]      Warehouse */
     int32_t *load;          /* [E][N]      MaterialTransport */
     int32_t *zone_load;     /* [E][2] */
     int32_t *messages;      /* [E][4] */
+    uint8_t *grid;          /* [E][8*12]   ArcticTransport terrain: 0 normal, 1 ice, 2 water, 3 goal */
+    int32_t *goal_col;      /* [E]         ArcticTransport goal_loc[1] (goal_loc[0] is always 1) */
+    uint8_t *pixel_type;    /* [E][N]      ArcticTransport Agent.pixel_type (read by the NEXT step's goals) */
+    uint8_t *reached_goal;  /* [E][N]      ArcticTransport Agent.reached_goal */
     /* Optional rollout statistics (all four NULL, or all four set), the on-device form of the
      * accumulators in utilities/misc.py:151-206 (episodeReward, episodeSteps, totalReward): */
     float *ep_return;       /* [E] return of the running episode */

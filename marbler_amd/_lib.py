@@ -43,7 +43,9 @@ class RgScenarioParams(C.Structure):
         ("violation_reward", C.c_float),
         ("load_reward", C.c_float), ("unload_reward", C.c_float), ("goal_width", C.c_float),
         ("unload_multiplier", C.c_float), ("load_multiplier", C.c_float), ("end_goal_width", C.c_float),
-        ("zone1_radius", C.c_float),
+        ("zone1_radius", C.c_float), ("reward_scaler", C.c_float),
+        ("arctic_normal_step", C.c_float), ("arctic_slow_step", C.c_float), ("arctic_fast_step", C.c_float),
+        ("not_reached_penalty", C.c_float), ("dist_multiplier", C.c_float),
         ("agent_grid", RgGrid), ("prey_grid", RgGrid), ("keep_theta", C.c_int32), ("shared_reward", C.c_int32),
         ("zone1_mean", C.c_float), ("zone1_std", C.c_float), ("zone2_mean", C.c_float),
         ("zone2_std", C.c_float),
@@ -54,7 +56,9 @@ class RgState(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("carry_dist", C.c_void_p), ("episode_steps", C.c_void_p),
                 ("reset_count", C.c_void_p), ("prey_loc", C.c_void_p), ("prey_sensed", C.c_void_p),
                 ("prey_captured", C.c_void_p), ("loaded", C.c_void_p), ("load", C.c_void_p),
-                ("zone_load", C.c_void_p), ("messages", C.c_void_p), ("ep_return", C.c_void_p),
+                ("zone_load", C.c_void_p), ("messages", C.c_void_p), ("grid", C.c_void_p),
+                ("goal_col", C.c_void_p), ("pixel_type", C.c_void_p), ("reached_goal", C.c_void_p),
+                ("ep_return", C.c_void_p),
                 ("done_return_sum", C.c_void_p), ("done_count", C.c_void_p), ("done_steps_sum", C.c_void_p)]
 
 

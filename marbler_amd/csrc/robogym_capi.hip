@@ -32,7 +32,7 @@ static int fail(int code, const char *fmt, const char *detail = "") {
 
 static int check_params(const rg_scenario_params *p) {
     if (!p) return fail(-1, "params is NULL");
-    if (p->scenario < RG_SCN_PREDATOR_CAPTURE_PREY || p->scenario > RG_SCN_MATERIAL_TRANSPORT)
+    if (p->scenario < RG_SCN_PREDATOR_CAPTURE_PREY || p->scenario > RG_SCN_ARCTIC_TRANSPORT)
         return fail(-2, "unknown scenario id");
     if (p->n_agents < 1 || p->n_agents > RG_MAX_AGENTS) return fail(-3, "n_agents must be in 1..16");
     if (p->update_frequency < 1 || p->controller_period < 1) return fail(-4, "update_frequency / controller_period < 1");
@@ -55,6 +55,14 @@ static int check_params(const rg_scenario_params *p) {
     } else if (p->scenario == RG_SCN_WAREHOUSE) {
         const int nb = p->num_neighbors >= p->n_agents - 1 ? p->n_agents - 1 : p->num_neighbors;
         if (p->obs_dim < 3 * (nb + 1)) return fail(-10, "obs_dim too small for Warehouse");
+    } else if (p->scenario == RG_SCN_SIMPLE) {
+        if (p->num_prey != 1) return fail(-8, "Simple has one goal (num_prey = 1)");
+        const rg_grid &q = p->prey_grid;
+        if (q.nx < 1 || q.ny < 1 || q.nx * q.ny <= 1 || q.nx * q.ny > 64) return fail(-9, "goal reset grid must have 1 < nx*ny <= 64");
+        if (p->obs_dim < 2 * (p->n_agents + 1)) return fail(-10, "obs_dim too small for Simple");
+    } else if (p->scenario == RG_SCN_ARCTIC_TRANSPORT) {
+        if (p->n_agents != 4) return fail(-3, "ArcticTransport has exactly 4 agents");
+        if (p->obs_dim < 30) return fail(-10, "obs_dim too small for ArcticTransport");
     } else {
         if (p->obs_dim < (p->capability_aware ? 11 : 9)) return fail(-10, "obs_dim too small for MaterialTransport");
     }
@@ -120,6 +128,14 @@ int rg_bind_state(rg_handle *h, const rg_state *st) {
             break;
         case RG_SCN_WAREHOUSE:
             if (!st->loaded) return fail(-21, "Warehouse needs loaded");
+            break;
+        case RG_SCN_SIMPLE:
+            if (!st->prey_loc) return fail(-21, "Simple needs prey_loc (its goal)");
+            break;
+        case RG_SCN_ARCTIC_TRANSPORT:
+            if (!st->grid || !st->goal_col || !st->pixel_type || !st->reached_goal)
+                return fail(-21, "ArcticTransport needs grid, goal_col, pixel_type, reached_goal");
+            if (reinterpret_cast<uintptr_t>(st->grid) & 3u) return fail(-26, "grid must be 4-byte aligned");
             break;
         default:
             if (!st->load || !st->zone_load || !st->messages)

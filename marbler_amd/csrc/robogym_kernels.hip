@@ -253,6 +253,7 @@ struct alignas(16) Lds {
     float own[WAVE][8];                      // each agent's own-observation row (<= 6 floats)
     float ax[WAVE], ay[WAVE];                // MaterialTransport sequential replay / reward sum
     int aload[WAVE];
+    uint8_t grid[WAVE / GW][RG_ARCTIC_ROWS * RG_ARCTIC_COLS];  // ArcticTransport terrain of the env
     uint32_t draws[WAVE / GW][MAX_DRAWS];    // reset: Philox output
     uint8_t perm[WAVE / GW][2][64];          // reset: Fisher-Yates permutations of the grid cells (agents, prey)
     uint8_t sel[WAVE / GW][2][64];           // reset: chosen cells
@@ -319,7 +320,53 @@ template <int SCN, int GW>
 __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, int e, int g, int ag, bool do_reset) {
     const rg_scenario_params &p = a.p;
     const int N = p.n_agents;
-    const int P = (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) ? p.num_prey : 0;
+    if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+        // ArcticTransport.py:56-82: fixed start poses; terrain grid uniform in {0,1,2} (draws 0..95,
+        // row-major), goal column uniform in 1..11 (draw 96), goal block 2x2 in rows 0-1, row 7
+        // columns 1..10 cleared.  (The reference draws the column from Python's `random`.)
+        constexpr int CELLS = RG_ARCTIC_ROWS * RG_ARCTIC_COLS;
+        int32_t episode = 0;
+        if (do_reset) {
+            episode = a.st.reset_count[e];
+            const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
+            for (int b = ag; 4 * b < CELLS + 1; b += GW) {
+                uint32_t blk[4];
+                philox4x32_10(static_cast<uint32_t>(ge), static_cast<uint32_t>(ge >> 32),
+                              static_cast<uint32_t>(episode), static_cast<uint32_t>(b),
+                              static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32), blk);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) lds.draws[g][4 * b + t] = blk[t];
+            }
+        }
+        __syncthreads();
+        if (do_reset) {
+            const int gc = 1 + static_cast<int>((static_cast<uint64_t>(lds.draws[g][CELLS]) * 11u) >> 32);
+            for (int i = ag; i < CELLS; i += GW) {
+                const int row = i / RG_ARCTIC_COLS, col = i - row * RG_ARCTIC_COLS;
+                int val = static_cast<int>((static_cast<uint64_t>(lds.draws[g][i]) * 3u) >> 32);
+                if (row <= 1 && (col == gc || col == gc - 1)) val = 3;
+                if (row == 7 && col >= 1 && col <= 10) val = 0;
+                a.st.grid[static_cast<size_t>(e) * CELLS + i] = static_cast<uint8_t>(val);
+            }
+            if (ag < N) {
+                float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
+                X[ag] = ag == 0 ? -0.3f : ag == 1 ? 0.3f : ag == 2 ? -0.9f : 0.9f;  // ArcticTransport.py:30-33
+                X[N + ag] = -0.8f;
+                X[2 * N + ag] = 1.57079637050628662109375f;
+                a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
+                a.st.pixel_type[static_cast<size_t>(e) * N + ag] = 0;
+                a.st.reached_goal[static_cast<size_t>(e) * N + ag] = 0;
+            }
+            if (ag == 0) {
+                a.st.goal_col[e] = gc;
+                a.st.reset_count[e] = episode + 1;
+                a.st.episode_steps[e] = 0;
+            }
+        }
+        return;
+    }
+    constexpr bool HAS_PREY = (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) || (SCN == RG_SCN_SIMPLE);
+    const int P = HAS_PREY ? p.num_prey : 0;  // Simple: its single goal is drawn like one prey
     constexpr int ZD = (SCN == RG_SCN_MATERIAL_TRANSPORT) ? 4 : 0;
     const int ndraws = ZD + 2 * N + P;
     int32_t episode = 0;
@@ -359,7 +406,7 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
             a.st.zone_load[2 * e + ag] = normal_int(lds.draws[g][2 * ag], lds.draws[g][2 * ag + 1], mean, sd);
         }
     }
-    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
+    if constexpr (HAS_PREY) {
         if (do_reset) {
             for (int i = ag; i < P; i += GW) {
                 float x, y;
@@ -367,8 +414,10 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
                 float *pl = a.st.prey_loc + (static_cast<size_t>(e) * P + i) * 2;
                 pl[0] = x;
                 pl[1] = y;
-                a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
-                a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
+                if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
+                    a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
+                    a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
+                }
             }
         }
     }
@@ -510,6 +559,9 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     // scenario state
     uint32_t sen_lo = 0, sen_hi = 0, cap_lo = 0, cap_hi = 0;  // PCP prey flags as bit masks (P <= 64)
     uint8_t loaded = 0;                                      // Warehouse
+    float goal_x = 0.0f, goal_y = 0.0f;                      // Simple
+    uint32_t grid_pre[6] = {0, 0, 0, 0, 0, 0};               // ArcticTransport
+    int goal_col = 1, pix = 0, reached = 0;
     int load = 0, zone0 = 0, zone1 = 0;                      // MaterialTransport
     int msg[4] = {0, 0, 0, 0};
     // PCP: the env's prey block is fetched into registers now (up to PRE floats per lane, i.e.
@@ -517,6 +569,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     // hides behind the sub-step loop; larger P take the direct copy below.
     constexpr int PRE = 4;
     float pre[PRE] = {0.0f, 0.0f, 0.0f, 0.0f};
+    static_assert(SCN != RG_SCN_ARCTIC_TRANSPORT || GW == 4, "ArcticTransport is a 4-agent scenario");
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
         if (env_ok) {
@@ -547,6 +600,23 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         }
     } else if constexpr (SCN == RG_SCN_WAREHOUSE) {
         if (lane_ok) loaded = a.st.loaded[eN + ag];
+    } else if constexpr (SCN == RG_SCN_SIMPLE) {
+        if (env_ok) {
+            goal_x = a.st.prey_loc[static_cast<size_t>(e) * 2];
+            goal_y = a.st.prey_loc[static_cast<size_t>(e) * 2 + 1];
+        }
+    } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+        if (env_ok) {
+            // 96 terrain bytes = 24 dwords: 6 per lane of the group (GW = 4)
+            const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(a.st.grid + static_cast<size_t>(e) * 96);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) grid_pre[t] = gsrc[ag * 6 + t];
+            goal_col = a.st.goal_col[e];
+        }
+        if (lane_ok) {
+            pix = a.st.pixel_type[eN + ag];
+            reached = a.st.reached_goal[eN + ag];
+        }
     } else {
         if (env_ok) {
 #pragma unroll
@@ -572,7 +642,13 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         float gx = x, gy = y;
         {
             const int mv = (SCN == RG_SCN_MATERIAL_TRANSPORT) ? act / 4 : act;
-            const float sd = agent_step;
+            float sd = agent_step;
+            if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {  // agent.py:89-113: drones 0,1; ice 2; water 3
+                const float nrm_s = p.arctic_normal_step, slow_s = p.arctic_slow_step, fast_s = p.arctic_fast_step;
+                const float water = pix == 1 ? slow_s : pix == 2 ? fast_s : nrm_s;
+                const float ice = pix == 1 ? fast_s : pix == 2 ? slow_s : nrm_s;
+                sd = ag < 2 ? fast_s : ag == 3 ? water : ice;
+            }
             const float cgx = clamp_spec(gx, p.left, p.right), cgy = clamp_spec(gy, p.up, p.down);
             const float lft = (gx - sd) > p.left ? (gx - sd) : p.left;
             const float rgt = (gx + sd) < p.right ? (gx + sd) : p.right;
@@ -854,6 +930,112 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 if (lane_ok) a.st.loaded[eN + ag] = loaded;
             }
         }
+    } else if constexpr (SCN == RG_SCN_SIMPLE) {  // scenarios/Simple/simple.py:155-225
+        lds.own[lane][0] = x;
+        lds.own[lane][1] = y;
+        __syncthreads();
+        if (lane_ok) {
+            obs_row[0] = x;
+            obs_row[1] = y;
+            obs_row[2 * N] = goal_x;
+            obs_row[2 * N + 1] = goal_y;
+        }
+        write_neighbour_obs<GW, 2>(lds, N, N - 1, ag, gbase, lane_ok, x, y, obs_row);  // all others, index order
+        if constexpr (!OBS_ONLY) {
+            if (viol) {
+                reward = p.violation_reward;
+                done = true;
+            } else {
+                const float dx = x - goal_x, dy = y - goal_y;
+                const float r = -(dx * dx + dy * dy);
+                reward = r * p.reward_scaler;
+                done = steps > p.max_episode_steps;
+            }
+        }
+    } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {  // ArcticTransport.py:84-143, agent.py:14-87
+        {
+            uint32_t *gdst = reinterpret_cast<uint32_t *>(&lds.grid[g][0]);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) gdst[ag * 6 + t] = grid_pre[t];
+        }
+        __syncthreads();
+        const uint8_t *grid = &lds.grid[g][0];
+        // get_cell_from_pose: int() truncates toward zero; /0.25 is exact
+        int row = -static_cast<int>((y - 1.0f) / 0.25f), col = static_cast<int>((x + 1.5f) / 0.25f);
+        row = row < 0 ? 0 : row > 7 ? 7 : row;
+        col = col < 0 ? 0 : col > 11 ? 11 : col;
+        if constexpr (!OBS_ONLY) {
+            pix = grid[row * 12 + col];
+            reached = reached | (pix == 3 ? 1 : 0);
+        }
+        const int here = grid[row * 12 + col];
+        lds.own[lane][0] = x;
+        lds.own[lane][1] = y;
+        lds.own[lane][2] = static_cast<float>(here);
+        lds.aload[lane] = row * 16 + col;
+        __syncthreads();
+        const float goalx = static_cast<float>(goal_col) * 0.25f - 1.5f, goaly = -1.0f * 0.25f + 0.75f;
+        if (lane_ok) {
+            obs_row[0] = x;
+            obs_row[1] = y;
+            obs_row[2] = static_cast<float>(here);
+            // the other three in the order of agent.py:42-69: {1,2,3} {0,2,3} {3,0,1} {2,0,1}
+            const int o0 = ag == 0 ? 1 : ag == 1 ? 0 : ag == 2 ? 3 : 2;
+            const int o1 = ag < 2 ? 2 : 0, o2 = ag < 2 ? 3 : 1;
+            const int oth[3] = {o0, o1, o2};
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                obs_row[3 + 3 * m + 0] = lds.own[gbase + oth[m]][0];
+                obs_row[3 + 3 * m + 1] = lds.own[gbase + oth[m]][1];
+                obs_row[3 + 3 * m + 2] = lds.own[gbase + oth[m]][2];
+            }
+            obs_row[12] = goalx;
+            obs_row[13] = goaly;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {  // the 8 cells around each drone, edges clamped
+                const int rc = lds.aload[gbase + i];
+                const int r_ = rc >> 4, c_ = rc & 15;
+                const int left = c_ > 0 ? c_ - 1 : c_, right = c_ < 11 ? c_ + 1 : c_;
+                const int up = r_ > 0 ? r_ - 1 : r_, down = r_ < 7 ? r_ + 1 : r_;
+                float *o = obs_row + 14 + 8 * i;
+                o[0] = static_cast<float>(grid[up * 12 + left]);
+                o[1] = static_cast<float>(grid[r_ * 12 + left]);
+                o[2] = static_cast<float>(grid[down * 12 + left]);
+                o[3] = static_cast<float>(grid[up * 12 + c_]);
+                o[4] = static_cast<float>(grid[down * 12 + c_]);
+                o[5] = static_cast<float>(grid[up * 12 + right]);
+                o[6] = static_cast<float>(grid[r_ * 12 + right]);
+                o[7] = static_cast<float>(grid[down * 12 + right]);
+            }
+        }
+        if constexpr (!OBS_ONLY) {
+            // shared reward over the two ground robots, in agent order (ArcticTransport.py:125-134)
+            const float dx = x - goalx, dy = y - goaly;
+            lds.ax[lane] = dx * dx + dy * dy;
+            lds.ay[lane] = static_cast<float>(pix * 2 + reached);
+            __syncthreads();
+            if (viol) {
+                reward = p.violation_reward;
+                done = true;
+            } else {
+                reward = 0.0f;
+                bool all_reached = true;
+#pragma unroll
+                for (int j = 2; j < 4; ++j) {
+                    const int pr = static_cast<int>(lds.ay[gbase + j]);
+                    const bool rj = (pr & 1) != 0;
+                    if (!rj) reward = reward + p.not_reached_penalty;
+                    if ((pr >> 1) != 3) reward = reward + p.dist_multiplier * lds.ax[gbase + j];
+                    all_reached = all_reached && rj;
+                }
+                done = steps > p.max_episode_steps;
+                if (!done) done = all_reached;
+            }
+            if (lane_ok) {
+                a.st.pixel_type[eN + ag] = static_cast<uint8_t>(pix);
+                a.st.reached_goal[eN + ag] = static_cast<uint8_t>(reached);
+            }
+        }
     } else {  // a16 MaterialTransport (MaterialTransport.py:113-189)
         if (lane_ok) {
             obs_row[0] = x;
@@ -1041,6 +1223,17 @@ hipError_t launch_step(const KernelArgs &a, bool obs_only, hipStream_t stream) {
         case RG_SCN_MATERIAL_TRANSPORT:
             return obs_only ? launch_step_scn<RG_SCN_MATERIAL_TRANSPORT, true>(a, stream)
                             : launch_step_scn<RG_SCN_MATERIAL_TRANSPORT, false>(a, stream);
+        case RG_SCN_SIMPLE:
+            return obs_only ? launch_step_scn<RG_SCN_SIMPLE, true>(a, stream)
+                            : launch_step_scn<RG_SCN_SIMPLE, false>(a, stream);
+        case RG_SCN_ARCTIC_TRANSPORT: {
+            const int grid = (a.E + 15) / 16;
+            if (obs_only)
+                hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, true>), dim3(grid), dim3(WAVE), 0, stream, a);
+            else
+                hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false>), dim3(grid), dim3(WAVE), 0, stream, a);
+            return hipGetLastError();
+        }
         default:
             return hipErrorInvalidValue;
     }
@@ -1054,6 +1247,11 @@ hipError_t launch_reset(const KernelArgs &a, hipStream_t stream) {
             return launch_reset_scn<RG_SCN_WAREHOUSE>(a, stream);
         case RG_SCN_MATERIAL_TRANSPORT:
             return launch_reset_scn<RG_SCN_MATERIAL_TRANSPORT>(a, stream);
+        case RG_SCN_SIMPLE:
+            return launch_reset_scn<RG_SCN_SIMPLE>(a, stream);
+        case RG_SCN_ARCTIC_TRANSPORT:
+            hipLaunchKernelGGL((reset_kernel<RG_SCN_ARCTIC_TRANSPORT, 4>), dim3((a.E + 15) / 16), dim3(WAVE), 0, stream, a);
+            return hipGetLastError();
         default:
             return hipErrorInvalidValue;
     }

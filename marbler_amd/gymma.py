@@ -1,0 +1,200 @@
+"""EPyMARL `gymma`-shaped adapters over VecRobotariumEnv.
+
+The reference trains through EPyMARL's `gymma` env wrapper (README.md:25-28:
+`--env-config=gymma with env_args.key="robotarium_gym:<Scenario>-v0" env_args.time_limit=...`),
+which is NOT part of /root/reference.  Its consumer contract, as recalled from upstream EPyMARL
+(`src/envs/__init__.py::_GymmaWrapper`) and consistent with the README's notes:
+
+  * `gym.make(key)` wrapped in `TimeLimit(max_episode_steps=time_limit)` and `FlattenObservation`;
+  * `step(actions) -> (float(sum(reward_n)), all(done_n), info)`;
+  * `get_obs()` = per-agent observations padded to the longest; `get_state()` = their concatenation;
+  * `get_avail_actions()` = all ones (every action always available), `get_total_actions()` = the
+    largest Discrete.n; `get_env_info()` = {state_shape, obs_shape, n_actions, n_agents, episode_limit};
+  * `reset()` returns `(get_obs(), get_state())`.
+
+`GymmaVecEnv` is the batched form: one object, E envs, torch tensors, one HIP launch per step --
+what EPyMARL's `parallel` runner gets from `batch_size_run` worker processes
+(scenarios/*/models/*.json: "runner": "parallel", "batch_size_run": 4-10).  `GymmaEnv` is the
+single-env form with EPyMARL's Python types, for dropping into an unmodified EPyMARL tree
+(register it under REGISTRY["gymma"]).
+"""
+import numpy as np
+import torch
+
+from .vec_env import VecRobotariumEnv
+
+N_ACTIONS = {"PredatorCapturePrey": 5, "Warehouse": 5, "MaterialTransport": 20, "Simple": 5, "ArcticTransport": 5}
+
+
+def scenario_from_key(key):
+    """'robotarium_gym:PredatorCapturePrey-v0' -> 'PredatorCapturePrey'."""
+    name = key.split(":")[-1]
+    if not name.endswith("-v0"):
+        raise ValueError(f"unknown gym key {key!r}")
+    return name[:-3]
+
+
+class GymmaVecEnv(object):
+    """E envs behind gymma's method names; everything is a device tensor with a leading E axis."""
+
+    def __init__(self, key, num_envs, time_limit, config_path=None, overrides=None, device="cuda:0", seed=0,
+                 env_offset=0):
+        self.scenario = scenario_from_key(key)
+        self.env = VecRobotariumEnv(self.scenario, num_envs, config_path=config_path, overrides=overrides,
+                                    device=device, seed=seed, env_offset=env_offset, auto_reset=True,
+                                    reference_reset_obs=True)
+        self.E, self.n_agents = self.env.E, self.env.N
+        self.episode_limit = int(time_limit)
+        self.n_actions = N_ACTIONS[self.scenario]
+        self.obs_size = self.env.D
+        self._elapsed = torch.zeros(self.E, dtype=torch.int32, device=self.env.device)
+        self._avail = torch.ones(self.E, self.n_agents, self.n_actions, dtype=torch.int32, device=self.env.device)
+        self._obs = self.env.obs
+
+    # -- gymma surface, batched
+    def reset(self):
+        self._obs = self.env.reset()
+        self._elapsed.zero_()
+        return self.get_obs(), self.get_state()
+
+    def step(self, actions):
+        """actions [E, N] int -> (reward [E] f32 = sum over agents, terminated [E] bool, info).
+        Envs that terminate (scenario rule or time limit) start a new episode; their next observation
+        is the reset observation (zeros, as the reference returns from reset())."""
+        obs, reward, done, info = self.env.step(actions)
+        self._elapsed += 1
+        truncated = (self._elapsed >= self.episode_limit) & ~done          # gym TimeLimit
+        if bool(truncated.any()):
+            self.env.reset(truncated)
+        ended = done | truncated
+        # the kernel has already reset `done` envs; gymma users see zeros after a reset (the reference's reset obs)
+        self._obs = torch.where(ended[:, None, None], torch.zeros_like(obs), obs)
+        self._terminal_obs = obs
+        self._elapsed[ended] = 0
+        out = dict(info)
+        out["TimeLimit.truncated"] = truncated
+        return reward.sum(dim=1), ended, out
+
+    def get_obs(self):
+        return self._obs
+
+    def get_obs_agent(self, agent_id):
+        return self._obs[:, agent_id]
+
+    def get_obs_size(self):
+        return self.obs_size
+
+    def get_state(self):
+        return self._obs.reshape(self.E, -1)
+
+    def get_state_size(self):
+        return self.n_agents * self.obs_size
+
+    def get_avail_actions(self):
+        return self._avail
+
+    def get_avail_agent_actions(self, agent_id):
+        return self._avail[:, agent_id]
+
+    def get_total_actions(self):
+        return self.n_actions
+
+    def get_env_info(self):
+        return {"state_shape": self.get_state_size(), "obs_shape": self.get_obs_size(),
+                "n_actions": self.get_total_actions(), "n_agents": self.n_agents,
+                "episode_limit": self.episode_limit}
+
+    def get_stats(self):
+        s, n, t = self.env.episode_stats()
+        return {"return_sum": float(s), "episodes": int(n), "steps": int(t)}
+
+    def render(self):
+        pass
+
+    def close(self):
+        self.env.close()
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self.env.seed = int(seed)
+        return self.env.seed
+
+    def save_replay(self):
+        pass
+
+
+class GymmaEnv(object):
+    """One env with EPyMARL's Python-level types (lists of numpy arrays, floats, bools)."""
+
+    def __init__(self, key, time_limit, pretrained_wrapper=None, seed=0, device="cuda:0", **kwargs):
+        self._v = GymmaVecEnv(key, 1, time_limit, device=device, seed=seed, overrides=kwargs or None)
+        # auto-reset is the runner's job in EPyMARL: keep the terminal state until reset() is called
+        self._v.env.auto_reset = False
+        self.n_agents = self._v.n_agents
+        self.episode_limit = self._v.episode_limit
+        self._done = False
+
+    def step(self, actions):
+        a = torch.as_tensor(np.asarray([int(x) for x in actions], dtype=np.int32).reshape(1, -1),
+                            device=self._v.env.device)
+        obs, reward, done, info = self._v.env.step(a)
+        self._v._elapsed += 1
+        truncated = bool(self._v._elapsed[0] >= self.episode_limit) and not bool(done[0])
+        self._v._obs = obs
+        out = {}
+        if truncated:
+            out["TimeLimit.truncated"] = True
+        viol = int(info["violation"][0])
+        if viol:
+            from .vec_env import VIOLATION_MESSAGES
+            out["message"] = VIOLATION_MESSAGES[viol]
+        return float(reward[0].sum()), bool(done[0]) or truncated, out
+
+    def reset(self):
+        self._v.env.reset()
+        self._v._obs = self._v.env.obs
+        self._v._elapsed.zero_()
+        return self.get_obs(), self.get_state()
+
+    def get_obs(self):
+        o = self._v._obs[0].cpu().numpy()
+        return [o[i] for i in range(self.n_agents)]
+
+    def get_obs_agent(self, agent_id):
+        return self._v._obs[0, agent_id].cpu().numpy()
+
+    def get_obs_size(self):
+        return self._v.get_obs_size()
+
+    def get_state(self):
+        return self._v._obs[0].reshape(-1).cpu().numpy()
+
+    def get_state_size(self):
+        return self._v.get_state_size()
+
+    def get_avail_actions(self):
+        return [[1] * self._v.n_actions for _ in range(self.n_agents)]
+
+    def get_avail_agent_actions(self, agent_id):
+        return [1] * self._v.n_actions
+
+    def get_total_actions(self):
+        return self._v.n_actions
+
+    def get_env_info(self):
+        return self._v.get_env_info()
+
+    def render(self):
+        pass
+
+    def close(self):
+        self._v.close()
+
+    def seed(self, seed=None):
+        return self._v.seed(seed)
+
+    def save_replay(self):
+        pass
+
+    def get_stats(self):
+        return {}

@@ -14,7 +14,7 @@ import yaml
 
 from ._lib import MAX_AGENTS, MAX_PREY, RgGrid, RgScenarioParams
 
-SCENARIO_IDS = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2}
+SCENARIO_IDS = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2, "Simple": 3, "ArcticTransport": 4}
 COLLISION_VARIANTS = {"center": 0, "offset": 1}
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 
@@ -143,6 +143,41 @@ def make_params(scenario, cfg):
         p.agent_grid = g
         p.prey_grid = _dummy_grid()
         p.keep_theta = 1
+    elif scenario == "Simple":
+        N = int(cfg["n_agents"])
+        p.n_agents = N
+        _check_agents(N)
+        p.num_prey = 1                                          # the single goal (simple.py:74)
+        p.obs_dim = 2 * (N + 1)                                 # simple.py:98
+        for a in range(N):
+            p.agent_step[a] = cfg["step_dist"]
+        p.reward_scaler = cfg["reward_scaler"]
+        p.violation_reward = -5.0                               # simple.py:174
+        thresh = cfg["ROBOT_INIT_RIGHT_THRESH"]
+        width = thresh - L                                     # simple.py:136-140
+        g = _grid(N, width, height, cfg["start_dist"], "agents")
+        g.ox1 = -(width / 2 - thresh)
+        p.agent_grid = g
+        width = R - cfg["PREY_INIT_LEFT_THRESH"]               # simple.py:143-146
+        q = _grid(1, width, height, cfg["step_dist"], "goal")
+        q.ox1 = (width / 2 - thresh)
+        p.prey_grid = q
+        p.keep_theta = 0
+    elif scenario == "ArcticTransport":
+        N = int(cfg["n_agents"])
+        if N != 4:
+            raise ValueError("ArcticTransport is hard-wired to 4 agents (ArcticTransport.py:26-31)")
+        p.n_agents = 4
+        p.obs_dim = 30                                          # ArcticTransport.py:19
+        p.arctic_normal_step, p.arctic_slow_step, p.arctic_fast_step = \
+            cfg["normal_step"], cfg["slow_step"], cfg["fast_step"]
+        p.not_reached_penalty, p.dist_multiplier = cfg["not_reached_penalty"], cfg["dist_multiplier"]
+        p.violation_reward = -30.0                              # ArcticTransport.py:103
+        g = _dummy_grid()                                       # fixed start poses (ArcticTransport.py:30-33)
+        g.nx, g.ny = 8, 1
+        p.agent_grid = g
+        p.prey_grid = _dummy_grid()
+        p.keep_theta = 0
     else:
         nf, ns = int(cfg["n_fast_agents"]), int(cfg["n_slow_agents"])
         N = int(cfg["n_agents"])

@@ -67,6 +67,8 @@ def scenario_spaces(scenario, params):
         n_act, lo, hi = 5, -5, 3
     elif scenario == "Warehouse":
         n_act, lo, hi = 5, -1.5, 1.5
+    elif scenario in ("Simple", "ArcticTransport"):     # simple.py:96-99, ArcticTransport.py:41-47
+        n_act, lo, hi = 5, -1.5, 3
     else:
         n_act, lo, hi = 20, -1.5, 1.5
     actions = Tuple(tuple(Discrete(n_act) for _ in range(N)))

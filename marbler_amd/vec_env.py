@@ -23,7 +23,8 @@ VIOLATION_MESSAGES = ("", "collision", "boundary", "collision_boundary")  # robo
 class VecRobotariumEnv(object):
     def __init__(self, scenario, num_envs, config_path=None, overrides=None, device="cuda:0", seed=0,
                  env_offset=0, auto_reset=True, reference_reset_obs=True, params=None, collect_qp_stats=False):
-        """scenario: 'PredatorCapturePrey' | 'Warehouse' | 'MaterialTransport' (wrapper.py:12-16).
+        """scenario: 'PredatorCapturePrey' | 'Warehouse' | 'MaterialTransport' | 'Simple' | 'ArcticTransport'
+        (wrapper.py:12-16).
         config_path / overrides: the reference's scenario YAML (same keys) and a dict of overrides.
         env_offset: global index of env 0 of this shard (RNG streams are keyed by global index).
         auto_reset: finished envs are reset inside the step launch.
@@ -65,6 +66,10 @@ class VecRobotariumEnv(object):
         self.load = torch.zeros(E, N, dtype=i32, device=dev)
         self.zone_load = torch.zeros(E, 2, dtype=i32, device=dev)
         self.messages = torch.zeros(E, 4, dtype=i32, device=dev)
+        self.grid = torch.zeros(E, 96, dtype=u8, device=dev)
+        self.goal_col = torch.ones(E, dtype=i32, device=dev)
+        self.pixel_type = torch.zeros(E, N, dtype=u8, device=dev)
+        self.reached_goal = torch.zeros(E, N, dtype=u8, device=dev)
         # ---- rollout statistics (misc.py:151-206 accumulators, on device)
         self.ep_return = torch.zeros(E, dtype=f32, device=dev)
         self.done_return_sum = torch.zeros(E, dtype=f32, device=dev)
@@ -86,7 +91,8 @@ class VecRobotariumEnv(object):
             raise _lib.RobogymError("rg_create failed: " + self.lib.rg_last_error().decode())
         st = _lib.RgState(*(t.data_ptr() for t in (
             self.poses, self.carry_dist, self.episode_steps, self.reset_count, self.prey_loc, self.prey_sensed,
-            self.prey_captured, self.loaded, self.load, self.zone_load, self.messages, self.ep_return,
+            self.prey_captured, self.loaded, self.load, self.zone_load, self.messages, self.grid, self.goal_col,
+            self.pixel_type, self.reached_goal, self.ep_return,
             self.done_return_sum, self.done_count, self.done_steps_sum)))
         _lib.check(self.lib.rg_bind_state(self._h, C.byref(st)), "rg_bind_state")
         self._io = _lib.RgStepIO(self.obs.data_ptr(), self.reward.data_ptr(), self.done_u8.data_ptr(),
@@ -150,7 +156,7 @@ class VecRobotariumEnv(object):
 
     # ------------------------------------------------------------------ state access (parity / checkpoints)
     STATE_KEYS = ("poses", "carry_dist", "episode_steps", "reset_count", "prey_loc", "prey_sensed", "prey_captured",
-                  "loaded", "load", "zone_load", "messages")
+                  "loaded", "load", "zone_load", "messages", "grid", "goal_col", "pixel_type", "reached_goal")
 
     def state_dict(self):
         return {k: getattr(self, k).clone() for k in self.STATE_KEYS}

@@ -16,7 +16,7 @@ from .params import default_config_path
 from .spaces import scenario_spaces
 from .vec_env import VIOLATION_MESSAGES, VecRobotariumEnv
 
-SCENARIOS = ("PredatorCapturePrey", "Warehouse", "MaterialTransport")
+SCENARIOS = ("PredatorCapturePrey", "Warehouse", "MaterialTransport", "Simple", "ArcticTransport")
 
 
 class _ScenarioFacade(object):
@@ -69,7 +69,7 @@ class _ScenarioFacade(object):
         pass
 
 
-env_dict = {name: name for name in SCENARIOS}  # wrapper.py:12-16 (Simple / ArcticTransport: not built yet)
+env_dict = {name: name for name in SCENARIOS}  # wrapper.py:12-16
 
 
 class Wrapper(object):

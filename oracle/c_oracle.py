@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 MAXN, MAXP = 16, 64
-SCN = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2}
+SCN = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2, "Simple": 3, "ArcticTransport": 4}
 
 
 class OrcParams(C.Structure):
@@ -40,7 +40,9 @@ class OrcParams(C.Structure):
         ("violation_reward", C.c_double),
         ("load_reward", C.c_double), ("unload_reward", C.c_double), ("goal_width", C.c_double),
         ("unload_multiplier", C.c_double), ("load_multiplier", C.c_double), ("end_goal_width", C.c_double),
-        ("zone1_radius", C.c_double),
+        ("zone1_radius", C.c_double), ("reward_scaler", C.c_double),
+        ("arctic_normal_step", C.c_double), ("arctic_slow_step", C.c_double), ("arctic_fast_step", C.c_double),
+        ("not_reached_penalty", C.c_double), ("dist_multiplier", C.c_double),
     ]
 
 
@@ -113,6 +115,22 @@ def params_from_config(scenario, cfg, collision_variant="offset", dtype=np.float
             p.agent_step[a] = cfg["step_dist"]
         p.load_reward, p.unload_reward, p.goal_width = cfg["load_reward"], cfg["unload_reward"], cfg["goal_width"]
         p.violation_reward = -5.0
+    elif scenario == "Simple":
+        N = int(cfg["n_agents"])
+        p.n_agents = N
+        p.num_prey = 1
+        p.obs_dim = 2 * (N + 1)
+        for a in range(N):
+            p.agent_step[a] = cfg["step_dist"]
+        p.reward_scaler = cfg["reward_scaler"]
+        p.violation_reward = -5.0
+    elif scenario == "ArcticTransport":
+        p.n_agents = 4
+        p.obs_dim = 30
+        p.arctic_normal_step, p.arctic_slow_step, p.arctic_fast_step = \
+            cfg["normal_step"], cfg["slow_step"], cfg["fast_step"]
+        p.not_reached_penalty, p.dist_multiplier = cfg["not_reached_penalty"], cfg["dist_multiplier"]
+        p.violation_reward = -30.0
     else:
         nf, ns = int(cfg["n_fast_agents"]), int(cfg["n_slow_agents"])
         N = int(cfg["n_agents"])
@@ -155,6 +173,10 @@ class OracleVecEnv(object):
         self.load = np.zeros((E, N), np.int32)
         self.zone_load = np.zeros((E, 2), np.int32)
         self.messages = np.zeros((E, 4), np.int32)
+        self.grid = np.zeros((E, 96), np.uint8)
+        self.goal_col = np.zeros(E, np.int32)
+        self.pixel_type = np.zeros((E, N), np.uint8)
+        self.reached_goal = np.zeros((E, N), np.uint8)
         self.obs = np.zeros((E, N, D), f)
         self.reward = np.zeros((E, N), f)
         self.done = np.zeros(E, np.uint8)
@@ -166,7 +188,7 @@ class OracleVecEnv(object):
         self._fn.restype = C.c_int
 
     STATE_KEYS = ("poses", "carry", "steps", "prey_loc", "prey_sensed", "prey_captured", "loaded", "load",
-                  "zone_load", "messages")
+                  "zone_load", "messages", "grid", "goal_col", "pixel_type", "reached_goal")
 
     def set_state(self, e, **kw):
         for k, v in kw.items():
@@ -185,7 +207,9 @@ class OracleVecEnv(object):
                         ("prey_loc", C.POINTER(ct)), ("prey_sensed", C.POINTER(C.c_uint8)),
                         ("prey_captured", C.POINTER(C.c_uint8)), ("loaded", C.POINTER(C.c_uint8)),
                         ("load", C.POINTER(C.c_int32)), ("zone_load", C.POINTER(C.c_int32)),
-                        ("messages", C.POINTER(C.c_int32))]
+                        ("messages", C.POINTER(C.c_int32)), ("grid", C.POINTER(C.c_uint8)),
+                        ("goal_col", C.POINTER(C.c_int32)), ("pixel_type", C.POINTER(C.c_uint8)),
+                        ("reached_goal", C.POINTER(C.c_uint8))]
 
         class Out(C.Structure):
             _fields_ = [("obs", C.POINTER(ct)), ("reward", C.POINTER(ct)), ("done", C.POINTER(C.c_uint8)),
@@ -194,7 +218,9 @@ class OracleVecEnv(object):
 
         st = St(_ptr(self.poses, ct), _ptr(self.carry, ct), _ptr(self.steps, C.c_int32), _ptr(self.prey_loc, ct),
                 _ptr(self.prey_sensed, C.c_uint8), _ptr(self.prey_captured, C.c_uint8), _ptr(self.loaded, C.c_uint8),
-                _ptr(self.load, C.c_int32), _ptr(self.zone_load, C.c_int32), _ptr(self.messages, C.c_int32))
+                _ptr(self.load, C.c_int32), _ptr(self.zone_load, C.c_int32), _ptr(self.messages, C.c_int32),
+                _ptr(self.grid, C.c_uint8), _ptr(self.goal_col, C.c_int32), _ptr(self.pixel_type, C.c_uint8),
+                _ptr(self.reached_goal, C.c_uint8))
         out = Out(_ptr(self.obs, ct), _ptr(self.reward, ct), _ptr(self.done, C.c_uint8), _ptr(self.dist, ct),
                   _ptr(self.viol, C.c_uint8), _ptr(self.remaining, C.c_int32), _ptr(self.qp_sweeps, C.c_int32))
         rc = self._fn(C.byref(self.p), C.c_int(self.E), C.byref(st), _ptr(actions, C.c_int32), C.byref(out))
@@ -258,3 +284,15 @@ def reset_env_f32(rp, seed, global_env, episode):
     fn(C.byref(rp), C.c_uint64(seed), C.c_uint64(global_env), C.c_uint32(episode), _ptr(poses, C.c_float),
        _ptr(prey, C.c_float), _ptr(zone, C.c_int32))
     return poses, prey, zone
+
+
+def reset_arctic_f32(seed, global_env, episode):
+    """ArcticTransport reset twin: (poses [3,4], grid [96] u8, goal_col)."""
+    poses = np.zeros((3, 4), np.float32)
+    grid = np.zeros(96, np.uint8)
+    gc = C.c_int32(0)
+    fn = lib().orc_reset_arctic_f32
+    fn.restype = None
+    fn(C.c_uint64(seed), C.c_uint64(global_env), C.c_uint32(episode), _ptr(poses, C.c_float),
+       _ptr(grid, C.c_uint8), C.byref(gc))
+    return poses, grid, gc.value

@@ -391,7 +391,160 @@ class MTPort(_ScenarioPort):  # scenarios/MaterialTransport/MaterialTransport.py
         return obs, [reward] * self.num_robots, [terminated] * self.num_robots, info
 
 
-PORTS = {"PredatorCapturePrey": PCPPort, "Warehouse": WarehousePort, "MaterialTransport": MTPort}
+class SimplePort(_ScenarioPort):  # scenarios/Simple/simple.py
+    def __init__(self, args):
+        self.args = args
+        self.num_robots = args.n_agents
+        if args.seed != -1:
+            np.random.seed(args.seed)
+        self.obs_dim = 2 * (self.num_robots + 1)
+        self.env = RoboEnvPort(self, args)
+
+    def _generate_step_goal_positions(self, actions):
+        goal = copy.deepcopy(self.agent_poses)
+        for i in range(self.num_robots):
+            goal[:, i] = _goal(goal[:, i], actions[i], self.args.step_dist, self.args)
+        return goal
+
+    def reset(self):
+        a = self.args
+        self.episode_steps = 0
+        width = a.ROBOT_INIT_RIGHT_THRESH - a.LEFT
+        height = a.DOWN - a.UP
+        self.agent_poses = generate_initial_locations(self.num_robots, width, height, a.ROBOT_INIT_RIGHT_THRESH,
+                                                      start_dist=a.start_dist)
+        width = a.RIGHT - a.PREY_INIT_LEFT_THRESH
+        self.goal_loc = generate_initial_locations(1, width, height, a.ROBOT_INIT_RIGHT_THRESH,
+                                                   start_dist=a.step_dist, spawn_left=False)[:2].T
+        self.env.reset()
+        return [[0] * self.obs_dim] * self.num_robots
+
+    def step(self, actions_):
+        a = self.args
+        self.episode_steps += 1
+        info = {}
+        message, dist = self.env.step(actions_)
+        own = [np.array(self.agent_poses[:2, k]) for k in range(self.num_robots)]
+        obs = []
+        for k in range(self.num_robots):
+            o = own[k]
+            for j in range(self.num_robots):
+                if j != k:
+                    o = np.concatenate((o, own[j]))
+            obs.append(np.concatenate((o, self.goal_loc.reshape(-1))))
+        if message == '':
+            rewards = []
+            for k in range(self.num_robots):
+                r = -(np.sum(np.square(self.agent_poses[:2, k].reshape(1, 2) - self.goal_loc.reshape(1, 2))))
+                r *= a.reward_scaler
+                rewards.append(r)
+            terminated = self.episode_steps > a.max_episode_steps
+        else:
+            rewards = [-5] * self.num_robots
+            terminated = True
+            info['message'] = message       # the reference files it under 'remaining' (simple.py:176)
+        info['dist_travelled'] = dist
+        return obs, rewards, [terminated] * self.num_robots, info
+
+
+class ArcticPort(_ScenarioPort):  # scenarios/ArcticTransport/{ArcticTransport.py, agent.py}
+    TYPES = ('drone', 'drone', 'ice', 'water')
+    OTHERS = ((1, 2, 3), (0, 2, 3), (3, 0, 1), (2, 0, 1))
+
+    def __init__(self, args):
+        import math
+        self.args = args
+        self.num_robots = args.n_agents
+        assert self.num_robots == 4
+        self.start_poses = np.array([[-.3, .3, -.9, .9], [-.8] * 4, [math.pi / 2] * 4])
+        if args.seed != -1:
+            np.random.seed(args.seed)
+        self.env = RoboEnvPort(self, args)
+
+    def _step_dist(self, k):
+        a, pix, t = self.args, self.pixel_type[k], self.TYPES[k]
+        if t == 'drone':
+            return a.fast_step
+        if t == 'water':
+            return a.slow_step if pix == 1 else a.fast_step if pix == 2 else a.normal_step
+        return a.fast_step if pix == 1 else a.slow_step if pix == 2 else a.normal_step
+
+    def _generate_step_goal_positions(self, actions):
+        goal = copy.deepcopy(self.agent_poses)
+        for i in range(self.num_robots):
+            goal[:, i] = _goal(goal[:, i], actions[i], self._step_dist(i), self.args)
+        return goal
+
+    def reset(self):
+        import random
+        self.episode_steps = 0
+        self.pixel_type = [0] * 4
+        self.reached_goal = [False] * 4
+        self.agent_poses = copy.deepcopy(self.start_poses)
+        self.grid = np.random.randint(3, size=(8, 12))
+        c = random.randint(1, 11)
+        self.grid[0][c] = self.grid[0][c - 1] = self.grid[1][c] = self.grid[1][c - 1] = 3
+        self.grid[7][1:11] = np.array([0] * 10)
+        self.goal_loc = [1, c]
+        self.env.reset()
+        return [[0] * 30] * 4
+
+    @staticmethod
+    def pose_from_cell(cell):
+        return [cell[1] * .25 - 1.5, (-cell[0] * .25 + .75)]
+
+    @staticmethod
+    def cell_from_pose(pose):
+        cell = [-int((pose[1] - 1) / .25), int((pose[0] + 1.5) / .25)]
+        cell[0] = 0 if cell[0] < 0 else 7 if cell[0] > 7 else cell[0]
+        cell[1] = 0 if cell[1] < 0 else 11 if cell[1] > 11 else cell[1]
+        return cell
+
+    def step(self, actions_):
+        a = self.args
+        self.episode_steps += 1
+        info = {}
+        message, dist = self.env.step(actions_)
+        poses, grid = self.agent_poses, self.grid
+        cells = [self.cell_from_pose(poses[:2, i]) for i in range(4)]
+        goal = self.pose_from_cell(self.goal_loc)
+        obs = []
+        for k in range(4):
+            self.pixel_type[k] = grid[cells[k][0], cells[k][1]]
+            if self.pixel_type[k] == 3:
+                self.reached_goal[k] = True
+            o = [*poses[:2, k], self.pixel_type[k]]
+            for j in self.OTHERS[k]:
+                o += [*poses[:2, j], grid[cells[j][0], cells[j][1]]]
+            o += goal
+            for i in range(2):
+                r, c = cells[i]
+                left, right = (c - 1 if c > 0 else c), (c + 1 if c < 11 else c)
+                up, down = (r - 1 if r > 0 else r), (r + 1 if r < 7 else r)
+                o += [grid[up, left], grid[r, left], grid[down, left], grid[up, c], grid[down, c],
+                      grid[up, right], grid[r, right], grid[down, right]]
+            obs.append(np.array(o, dtype=np.float64))
+        if message == '':
+            reward = 0
+            for k in (2, 3):
+                if not self.reached_goal[k]:
+                    reward += a.not_reached_penalty
+                if self.pixel_type[k] != 3:
+                    d = np.linalg.norm(poses[:2, k] - goal)
+                    reward += a.dist_multiplier * d ** 2
+            terminated = self.episode_steps > a.max_episode_steps
+            if not terminated:
+                terminated = self.reached_goal[2] and self.reached_goal[3]
+        else:
+            reward = -30
+            terminated = True
+            info['message'] = message
+        info['dist_travelled'] = dist
+        return obs, [reward] * 4, [terminated] * 4, info
+
+
+PORTS = {"PredatorCapturePrey": PCPPort, "Warehouse": WarehousePort, "MaterialTransport": MTPort,
+         "Simple": SimplePort, "ArcticTransport": ArcticPort}
 
 
 def make_port(scenario, cfg):

@@ -98,6 +98,30 @@ static void sample_cells(draws_t *d, const orc_grid *g, int count, float *outx, 
 }
 
 /* One env: writes poses [3][N], prey_loc [P][2], zone_load [2].  episode = the env's reset_count. */
+/* ArcticTransport (ArcticTransport.py:56-82): fixed poses; grid[96] uniform {0,1,2} from draws 0..95
+ * (row-major), goal column 1..11 from draw 96, 2x2 goal block in rows 0-1, row 7 columns 1..10 cleared. */
+void orc_reset_arctic_f32(uint64_t seed, uint64_t global_env, uint32_t episode, float *poses, uint8_t *grid,
+                          int32_t *goal_col) {
+    draws_t d = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)global_env, (uint32_t)(global_env >> 32), episode, 0};
+    uint32_t cell[96];
+    for (int i = 0; i < 96; ++i) cell[i] = draw_u32(&d);
+    int gc = 1 + (int)(((uint64_t)draw_u32(&d) * 11u) >> 32);
+    for (int i = 0; i < 96; ++i) {
+        int row = i / 12, col = i % 12;
+        int val = (int)(((uint64_t)cell[i] * 3u) >> 32);
+        if (row <= 1 && (col == gc || col == gc - 1)) val = 3;
+        if (row == 7 && col >= 1 && col <= 10) val = 0;
+        grid[i] = (uint8_t)val;
+    }
+    static const float sx[4] = {-0.3f, 0.3f, -0.9f, 0.9f};
+    for (int a = 0; a < 4; ++a) {
+        poses[a] = sx[a];
+        poses[4 + a] = -0.8f;
+        poses[8 + a] = 1.57079637050628662109375f;
+    }
+    *goal_col = gc;
+}
+
 void orc_reset_env_f32(const orc_reset_params *p, uint64_t seed, uint64_t global_env, uint32_t episode, float *poses,
                        float *prey_loc, int32_t *zone_load) {
     draws_t d = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)global_env, (uint32_t)(global_env >> 32), episode, 0};
@@ -112,5 +136,6 @@ void orc_reset_env_f32(const orc_reset_params *p, uint64_t seed, uint64_t global
                    3.1415927410125732421875f;
         poses[2 * N + i] = p->keep_theta ? th : 0.0f;
     }
-    if (p->scenario == ORC_SCN_PCP) sample_cells(&d, &p->prey_grid, p->num_prey, prey_loc, prey_loc + 1, 2);
+    if (p->scenario == ORC_SCN_PCP || p->scenario == ORC_SCN_SIMPLE)
+        sample_cells(&d, &p->prey_grid, p->num_prey, prey_loc, prey_loc + 1, 2);
 }

@@ -8,6 +8,8 @@
 #define ORC_SCN_PCP 0
 #define ORC_SCN_WAREHOUSE 1
 #define ORC_SCN_MT 2
+#define ORC_SCN_SIMPLE 3
+#define ORC_SCN_ARCTIC 4
 
 typedef struct orc_params {
     int32_t scenario;
@@ -39,6 +41,9 @@ typedef struct orc_params {
     double time_penalty, sense_reward, capture_reward, violation_reward;
     double load_reward, unload_reward, goal_width;
     double unload_multiplier, load_multiplier, end_goal_width, zone1_radius;
+    double reward_scaler;                                      /* Simple */
+    double arctic_normal_step, arctic_slow_step, arctic_fast_step; /* ArcticTransport */
+    double not_reached_penalty, dist_multiplier;
 } orc_params;
 
 /* reset sampler (a17) of sim_spec_v0: grid geometry as the host computes it in float64 from the

@@ -114,6 +114,10 @@ typedef struct {
     int32_t *load;          /* [E][N]     MaterialTransport */
     int32_t *zone_load;     /* [E][2] */
     int32_t *messages;      /* [E][4] */
+    uint8_t *grid;          /* [E][96]    ArcticTransport */
+    int32_t *goal_col;      /* [E] */
+    uint8_t *pixel_type;    /* [E][N] */
+    uint8_t *reached_goal;  /* [E][N] */
 } FN(orc_state);
 
 typedef struct {
@@ -367,6 +371,12 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
         /* a1 generate_goal (PCP agent.py:48-76, warehouse.py:19-45, MaterialTransport.py:19-46) */
         int mv = (p->scenario == ORC_SCN_MT) ? act[a] / 4 : act[a];
         REAL sd = R(p->agent_step[a]);
+        if (p->scenario == ORC_SCN_ARCTIC) { /* ArcticTransport/agent.py:89-113: drones 0,1; ice 2; water 3 */
+            int pix = st->pixel_type[(size_t)e * N + a];
+            if (a < 2) sd = R(p->arctic_fast_step);
+            else if (a == 3) sd = pix == 1 ? R(p->arctic_slow_step) : pix == 2 ? R(p->arctic_fast_step) : R(p->arctic_normal_step);
+            else sd = pix == 1 ? R(p->arctic_fast_step) : pix == 2 ? R(p->arctic_slow_step) : R(p->arctic_normal_step);
+        }
         REAL tx = x[a], ty = y[a];
         if (mv == 0) {
             REAL t = tx - sd;
@@ -630,6 +640,98 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
             }
             done = steps > p->max_episode_steps;
         }
+    } else if (p->scenario == ORC_SCN_SIMPLE) {
+        /* Simple (scenarios/Simple/simple.py:155-225): obs = own (x,y), the others in index order,
+         * the goal; dense per-agent reward -|p - goal|^2 * reward_scaler */
+        REAL *gl = st->prey_loc + (size_t)e * 2;
+        for (int a = 0; a < N; ++a) {
+            REAL *o = obs + (size_t)a * D;
+            int n = 0;
+            o[n++] = x[a];
+            o[n++] = y[a];
+            for (int j = 0; j < N; ++j)
+                if (j != a) {
+                    o[n++] = x[j];
+                    o[n++] = y[j];
+                }
+            o[n++] = gl[0];
+            o[n++] = gl[1];
+        }
+        if (viol) {
+            for (int a = 0; a < N; ++a) rew[a] = R(p->violation_reward);
+            done = 1;
+        } else {
+            for (int a = 0; a < N; ++a) {
+                REAL dx = x[a] - gl[0], dy = y[a] - gl[1];
+                REAL r = -(dx * dx + dy * dy);
+                rew[a] = r * R(p->reward_scaler);
+            }
+            done = steps > p->max_episode_steps;
+        }
+    } else if (p->scenario == ORC_SCN_ARCTIC) {
+        /* ArcticTransport (ArcticTransport.py:84-143, agent.py:14-87) */
+        const uint8_t *grid = st->grid + (size_t)e * 96;
+        uint8_t *pix = st->pixel_type + (size_t)e * N, *reached = st->reached_goal + (size_t)e * N;
+        int gc = st->goal_col[e];
+        int row[4], col[4];
+        for (int a = 0; a < 4; ++a) { /* get_cell_from_pose: int() truncates toward zero */
+            int r_ = -(int)((y[a] - R(1)) / R(0.25)), c_ = (int)((x[a] + R(1.5)) / R(0.25));
+            row[a] = r_ < 0 ? 0 : r_ > 7 ? 7 : r_;
+            col[a] = c_ < 0 ? 0 : c_ > 11 ? 11 : c_;
+        }
+        REAL goalx = (REAL)gc * R(0.25) - R(1.5), goaly = R(-1) * R(0.25) + R(0.75);
+        static const int others[4][3] = {{1, 2, 3}, {0, 2, 3}, {3, 0, 1}, {2, 0, 1}};
+        for (int a = 0; a < 4; ++a) {
+            REAL *o = obs + (size_t)a * D;
+            int n = 0;
+            pix[a] = grid[row[a] * 12 + col[a]];
+            if (pix[a] == 3) reached[a] = 1;
+            o[n++] = x[a];
+            o[n++] = y[a];
+            o[n++] = (REAL)pix[a];
+            for (int m = 0; m < 3; ++m) {
+                int j = others[a][m];
+                o[n++] = x[j];
+                o[n++] = y[j];
+                o[n++] = (REAL)grid[row[j] * 12 + col[j]];
+            }
+            o[n++] = goalx;
+            o[n++] = goaly;
+            for (int i = 0; i < 2; ++i) { /* the 8 cells around each drone, edges clamped */
+                int left = col[i] > 0 ? col[i] - 1 : col[i], right = col[i] < 11 ? col[i] + 1 : col[i];
+                int up = row[i] > 0 ? row[i] - 1 : row[i], down = row[i] < 7 ? row[i] + 1 : row[i];
+                o[n++] = (REAL)grid[up * 12 + left];
+                o[n++] = (REAL)grid[row[i] * 12 + left];
+                o[n++] = (REAL)grid[down * 12 + left];
+                o[n++] = (REAL)grid[up * 12 + col[i]];
+                o[n++] = (REAL)grid[down * 12 + col[i]];
+                o[n++] = (REAL)grid[up * 12 + right];
+                o[n++] = (REAL)grid[row[i] * 12 + right];
+                o[n++] = (REAL)grid[down * 12 + right];
+            }
+        }
+        REAL r;
+        if (viol) {
+            r = R(p->violation_reward);
+            done = 1;
+        } else {
+            r = R(0);
+            for (int a = 2; a < 4; ++a) { /* only the non-drones count */
+                if (!reached[a]) r = r + R(p->not_reached_penalty);
+                if (pix[a] != 3) {
+                    REAL dx = x[a] - goalx, dy = y[a] - goaly;
+#if ORC_IS_F32
+                    r = r + R(p->dist_multiplier) * (dx * dx + dy * dy); /* float spec: dist^2 without the sqrt */
+#else
+                    REAL dd = SQRT(dx * dx + dy * dy);
+                    r = r + R(p->dist_multiplier) * (dd * dd);
+#endif
+                }
+            }
+            done = steps > p->max_episode_steps;
+            if (!done) done = reached[2] && reached[3];
+        }
+        for (int a = 0; a < N; ++a) rew[a] = r;
     } else { /* ORC_SCN_MT */
         /* a16 (MaterialTransport.py:113-189) */
         int32_t *load = st->load + (size_t)e * N, *zone = st->zone_load + (size_t)e * 2, *msg = st->messages + (size_t)e * 4;
@@ -706,6 +808,7 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
 int FN(orc_step)(const orc_params *p, int E, const FN(orc_state) * st, const int32_t *actions, const FN(orc_out) * out) {
     if (p->n_agents < 1 || p->n_agents > ORC_MAXN) return -1;
     if (p->scenario == ORC_SCN_PCP && (p->num_prey < 0 || p->num_prey > ORC_MAXP)) return -2;
+    if (p->scenario == ORC_SCN_ARCTIC && p->n_agents != 4) return -3;
     for (int e = 0; e < E; ++e) FN(step_env)(p, e, st, actions, out);
     return 0;
 }

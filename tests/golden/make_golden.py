@@ -99,7 +99,37 @@ def policy_mt(w, rng, eps):
     return acts
 
 
-POLICY = {"PredatorCapturePrey": policy_pcp, "Warehouse": policy_warehouse, "MaterialTransport": policy_mt}
+def policy_simple(w, rng, eps):
+    s = w.env
+    acts = []
+    for a in range(s.num_robots):
+        if rng.rand() < eps:
+            acts.append(int(rng.randint(5)))
+            continue
+        dx, dy = np.asarray(s.goal_loc).reshape(-1) - s.agent_poses[:2, a]
+        acts.append(4 if np.hypot(dx, dy) < 0.15 else _toward(dx, dy))
+    return acts
+
+
+def policy_arctic(w, rng, eps):
+    s = w.env
+    acts = []
+    gx, gy = s.get_pose_from_cell(s.goal_loc)
+    for a in range(s.num_robots):
+        if rng.rand() < eps:
+            acts.append(int(rng.randint(5)))
+            continue
+        if a < 2:   # drones wander ahead of the ground robots
+            tx, ty = gx + (0.4 if a else -0.4), 0.2
+        else:
+            tx, ty = gx - 0.12 + 0.25 * (a - 2) * 0.9, gy + 0.1
+        dx, dy = tx - s.agent_poses[0, a], ty - s.agent_poses[1, a]
+        acts.append(4 if np.hypot(dx, dy) < 0.12 else _toward(dx, dy))
+    return acts
+
+
+POLICY = {"PredatorCapturePrey": policy_pcp, "Warehouse": policy_warehouse, "MaterialTransport": policy_mt,
+          "Simple": policy_simple, "ArcticTransport": policy_arctic}
 
 # ----------------------------------------------------------------------------- cases
 CASES = [
@@ -118,6 +148,10 @@ CASES = [
     ("mt_n6_random", "MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25},
      [95], 80, 1.0),
     ("mt_n4_capaware", "MaterialTransport", {"capability_aware": True}, [97], 60, 0.3),
+    ("simple_n4_default", "Simple", {}, [101, 102], 110, 0.3),
+    ("simple_n6_random", "Simple", {"n_agents": 6}, [105], 110, 1.0),
+    ("arctic_default", "ArcticTransport", {}, [111, 112, 113], 130, 0.25),
+    ("arctic_random", "ArcticTransport", {}, [115], 130, 1.0),
 ]
 
 
@@ -152,7 +186,7 @@ def forced_violation_cases():
     out = []
     for scenario, ov in (("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}),
                          ("Warehouse", {"n_agents": 8}),
-                         ("MaterialTransport", {})):
+                         ("MaterialTransport", {}), ("Simple", {}), ("ArcticTransport", {})):
         for kind in ("collision", "boundary", "both", "barrier_unsafe", "late_boundary"):
             ov2 = dict(ov)
             ov2["seed"] = 5
@@ -178,8 +212,8 @@ def forced_violation_cases():
             if kind == "barrier_unsafe":
                 # two robots inside each other's safety radius, commanded at each other: the
                 # certificate's unsafe branch (h < 0, gain 1e6) is active
-                P[0, 0], P[1, 0], P[2, 0] = 0.0, 0.0, 0.0
-                P[0, 1], P[1, 1], P[2, 1] = 0.19, 0.0, np.pi
+                P[0, 0], P[1, 0], P[2, 0] = 0.07, 0.06, 0.0     # off the 0.25 m ArcticTransport cell lines
+                P[0, 1], P[1, 1], P[2, 1] = 0.26, 0.06, np.pi
                 if scenario == "MaterialTransport":
                     acts[0], acts[1] = 1 * 4, 0 * 4
                 else:

@@ -81,7 +81,7 @@ def _install_stubs():
 
 
 _SCENARIO_DIR = {"PredatorCapturePrey": "PredatorCapturePrey", "Warehouse": "Warehouse",
-                 "MaterialTransport": "MaterialTransport"}
+                 "MaterialTransport": "MaterialTransport", "Simple": "Simple", "ArcticTransport": "ArcticTransport"}
 
 
 def load_reference_config(scenario):
@@ -94,6 +94,8 @@ def make_reference_wrapper(scenario, overrides, collision_variant="offset"):
     """Returns (wrapper, config_dict).  Stdout of the reference is swallowed (it prints on
     termination)."""
     _install_stubs()
+    import random as _pyrandom
+    _pyrandom.seed(int(overrides.get("seed", 0)) + 12345)   # ArcticTransport.py:72 draws from Python's `random`
     import rps.robotarium as rr
     rr.COLLISION_VARIANT = collision_variant
     rr._ERRORS.clear()
@@ -150,6 +152,13 @@ def snapshot_state(w, scenario):
         st["load"] = np.array([a.load for a in s.agents], dtype=np.int64)
         st["zone_load"] = np.array([s.zone1_load, s.zone2_load], dtype=np.int64)
         st["messages"] = np.array(s.messages, dtype=np.int64)
+    elif scenario == "Simple":
+        st["prey_loc"] = np.array(s.goal_loc, dtype=np.float64).reshape(1, 2).copy()   # the goal, as a 1-prey block
+    elif scenario == "ArcticTransport":
+        st["grid"] = np.array(s.grid, dtype=np.uint8).reshape(-1).copy()
+        st["goal_col"] = np.int64(s.goal_loc[1])
+        st["pixel_type"] = np.array([a.pixel_type for a in s.agents], dtype=np.uint8)
+        st["reached_goal"] = np.array([a.reached_goal for a in s.agents], dtype=np.uint8)
     return st
 
 
@@ -167,5 +176,10 @@ def step_record(w, scenario, actions):
     assert all(bool(d) == bool(done[0]) for d in done)
     rec["dist"] = np.array(info["dist_travelled"], dtype=np.float64)
     rec["viol"] = np.uint8(_MSG[info.get("message", "")])
-    rec["remaining"] = np.int64(info["remaining"]) if "remaining" in info else np.int64(-1)
+    rem = info.get("remaining", -1)
+    # Simple puts the violation STRING under 'remaining' (simple.py:176): recorded as the message code
+    if isinstance(rem, str):
+        rec["viol"] = np.uint8(_MSG[rem])
+        rem = -1
+    rec["remaining"] = np.int64(rem)
     return rec

@@ -7,8 +7,9 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STATE_KEYS = ("poses", "carry", "steps", "prey_loc", "prey_sensed", "prey_captured", "loaded", "load",
-              "zone_load", "messages")
+              "zone_load", "messages", "grid", "goal_col", "pixel_type", "reached_goal")
 GPU_NAME = {"carry": "carry_dist", "steps": "episode_steps"}
+FLAT = ("goal_col",)
 
 
 def golden_files():

@@ -42,7 +42,7 @@ def test_step_bit_exact_vs_f32_oracle(path, oracle_lib):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
             f"{name}: {np.sum(a.view(np.uint32) != b.view(np.uint32))} words differ, max |d| {np.abs(a - b).max()}"
     assert np.array_equal(post["episode_steps"], orc.steps)
-    for k in ("prey_sensed", "prey_captured", "loaded", "load", "zone_load", "messages"):
+    for k in ("prey_sensed", "prey_captured", "loaded", "load", "zone_load", "messages", "pixel_type", "reached_goal"):
         if "pre_" + k in g.files:
             assert np.array_equal(post[k], getattr(orc, k)), k
 
@@ -61,7 +61,7 @@ def test_step_vs_reference_golden(path):
     assert np.abs(post["poses"][:, :2] - g["post_poses"][:, :2]).max() <= tol
     # headings: reversing robots amplify rounding (DESIGN.md "float32 vs float64"); bound, not 1e-5
     assert angle_diff(post["poses"][:, 2], g["post_poses"][:, 2]).max() <= 5e-4
-    for k in ("prey_sensed", "prey_captured", "loaded", "load", "zone_load", "messages"):
+    for k in ("prey_sensed", "prey_captured", "loaded", "load", "zone_load", "messages", "pixel_type", "reached_goal"):
         if "post_" + k in g.files:
             assert np.array_equal(post[k], g["post_" + k]), k
     # observations: rows whose neighbour order / nearest prey hinges on a float32 near-tie are

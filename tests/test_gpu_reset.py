@@ -11,7 +11,10 @@ CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}),
          ("PredatorCapturePrey", {}),
          ("Warehouse", {"n_agents": 8}),
          ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}),
-         ("MaterialTransport", {})]
+         ("MaterialTransport", {}),
+         ("Simple", {}),
+         ("Simple", {"n_agents": 7, "start_dist": 0.25}),
+         ("ArcticTransport", {})]
 
 
 @pytest.mark.parametrize("scenario,ov", CASES)
@@ -27,10 +30,16 @@ def test_reset_bit_exact_and_shard_invariant(scenario, ov, oracle_lib):
     rc = env.reset_count.cpu().numpy()
     assert np.array_equal(rc, 1 + (np.arange(E) % 3 == 0))
     rp = oracle_reset_params(oracle_lib, env.params)
+    grid, gcol = env.grid.cpu().numpy(), env.goal_col.cpu().numpy()
     for e in range(E):
+        if scenario == "ArcticTransport":
+            p, gr, gc = oracle_lib.reset_arctic_f32(seed, e, int(rc[e]) - 1)
+            assert np.array_equal(poses[e].view(np.uint32), p.view(np.uint32)), e
+            assert np.array_equal(grid[e], gr) and gcol[e] == gc, e
+            continue
         p, q, z = oracle_lib.reset_env_f32(rp, seed, e, int(rc[e]) - 1)
         assert np.array_equal(poses[e].view(np.uint32), p.view(np.uint32)), e
-        if scenario == "PredatorCapturePrey":
+        if scenario in ("PredatorCapturePrey", "Simple"):
             assert np.array_equal(prey[e].view(np.uint32), q.view(np.uint32)), e
         if scenario == "MaterialTransport":
             assert np.array_equal(zone[e], z), e
@@ -44,6 +53,7 @@ def test_reset_bit_exact_and_shard_invariant(scenario, ov, oracle_lib):
     assert torch.equal(env2.poses, first.poses[150:250])
     assert torch.equal(env2.prey_loc, first.prey_loc[150:250])
     assert torch.equal(env2.zone_load, first.zone_load[150:250])
+    assert torch.equal(env2.grid, first.grid[150:250]) and torch.equal(env2.goal_col, first.goal_col[150:250])
     for x in (env, env2, first):
         x.close()
 
@@ -60,6 +70,8 @@ def test_reset_geometry_and_state(scenario, ov):
     env.load.fill_(5)
     env.prey_sensed.fill_(1)
     env.messages.fill_(3)
+    env.pixel_type.fill_(2)
+    env.reached_goal.fill_(1)
     obs = env.reset()
     torch.cuda.synchronize()
     assert float(obs.abs().max()) == 0.0                        # reference returns zeros from reset()
@@ -70,6 +82,23 @@ def test_reset_geometry_and_state(scenario, ov):
         assert int(env.loaded.max()) == 0
     if scenario == "MaterialTransport":
         assert int(env.load.max()) == 0 and int(env.messages.max()) == 0
+    if scenario == "ArcticTransport":
+        assert int(env.pixel_type.max()) == 0 and int(env.reached_goal.max()) == 0
+        P = env.poses.cpu().numpy()
+        assert np.allclose(P[:, 0], [-0.3, 0.3, -0.9, 0.9]) and np.allclose(P[:, 1], -0.8) and \
+            np.allclose(P[:, 2], np.pi / 2)
+        G = env.grid.cpu().numpy().reshape(E, 8, 12)
+        gc = env.goal_col.cpu().numpy()
+        assert gc.min() == 1 and gc.max() == 11 and abs(gc.mean() - 6) < 0.3
+        for e in range(0, E, 97):
+            c = gc[e]
+            assert (G[e, :2, c - 1:c + 1] == 3).all() and (G[e] == 3).sum() == 4
+            assert (G[e, 7, 1:11] == 0).all()
+        free = G[:, 2:7, :]                                     # rows untouched by the goal / the cleared row
+        frac = [(free == v).mean() for v in (0, 1, 2)]
+        assert all(abs(f - 1 / 3) < 0.01 for f in frac)
+        env.close()
+        return
     g = env.params.agent_grid
     P = env.poses.double().cpu().numpy()
     cx = (P[:, 0] - g.ox1 - g.ox2 + g.w2) / g.spacing
@@ -88,7 +117,7 @@ def test_reset_geometry_and_state(scenario, ov):
         assert th.min() >= -np.pi - 1e-6 and th.max() < np.pi + 1e-6 and abs(th.mean()) < 0.05
     else:
         assert np.abs(P[:, 2]).max() == 0.0
-    if scenario == "PredatorCapturePrey":
+    if scenario in ("PredatorCapturePrey", "Simple"):
         q = env.params.prey_grid
         L = env.prey_loc.double().cpu().numpy()
         px = np.round((L[:, :, 0] - q.ox1 + q.w2) / q.spacing).astype(int)

@@ -16,10 +16,23 @@ CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5
          ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}, 20, 160),
          ("MaterialTransport", {}, 20, 100),
          ("PredatorCapturePrey", {"predator": 6, "capture": 6, "n_agents": 12, "num_prey": 10, "start_dist": 0.25,
-                                  "num_neighbors": 4}, 5, 60)]
+                                  "num_neighbors": 4}, 5, 60),
+         ("Simple", {}, 5, 130),
+         ("Simple", {"n_agents": 6}, 5, 80),
+         ("ArcticTransport", {}, 5, 200)]
 
 
 def _oracle_reset(oracle_lib, orc, rp, seed, e, episode):
+    if orc.scenario == "ArcticTransport":
+        p, grid, gc = oracle_lib.reset_arctic_f32(seed, e, episode)
+        orc.poses[e] = p
+        orc.carry[e] = 0
+        orc.steps[e] = 0
+        orc.grid[e] = grid
+        orc.goal_col[e] = gc
+        orc.pixel_type[e] = 0
+        orc.reached_goal[e] = 0
+        return
     p, q, z = oracle_lib.reset_env_f32(rp, seed, e, episode)
     orc.poses[e] = p
     orc.carry[e] = 0

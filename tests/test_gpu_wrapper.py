@@ -1,0 +1,102 @@
+"""The single-env facade (marbler_amd.wrapper.Wrapper) returns what the reference's Wrapper returns,
+type for type (wrapper.py:36-44), and the gymma-shaped adapters reduce it the way EPyMARL does."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import yaml
+
+from helpers import GPU_NAME, GOLDEN_DIR, load_golden, pre_state
+
+pytestmark = pytest.mark.gpu
+
+MSG = {0: None, 1: "collision", 2: "boundary", 3: "collision_boundary"}
+FILES = ["pcp_n5", "warehouse_n8", "mt_n6", "simple_n4_default", "arctic_default", "viol_PredatorCapturePrey_both",
+         "viol_Warehouse_late_boundary", "viol_ArcticTransport_collision"]
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_wrapper_matches_reference_types_and_values(name):
+    import torch
+    from marbler_amd import Wrapper
+    g, scenario, cfg = load_golden(os.path.join(GOLDEN_DIR, name + ".npz"))
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        yaml.safe_dump(cfg, f)
+        path = f.name
+    try:
+        w = Wrapper(scenario, path)
+    finally:
+        os.unlink(path)
+    N = w.n_agents
+    assert len(w.action_space) == N and len(w.observation_space) == N
+    obs0 = w.reset()
+    assert isinstance(obs0, list) and len(obs0) == N and all(v == 0 for v in obs0[0])
+    st = pre_state(g)
+    rows = [t for t in range(len(g["actions"]))][:60]
+    rows += [int(t) for t in np.nonzero(g["done"])[0][:4]]
+    tol = 2e-5 if cfg["update_frequency"] > 29 else 1e-5
+    for t in rows:
+        w.env.vec.load_state_dict({GPU_NAME.get(k, k): torch.as_tensor(np.asarray(v[t:t + 1])) for k, v in st.items()})
+        obs, rew, done, info = w.step([int(a) for a in g["actions"][t]])
+        assert isinstance(obs, tuple) and len(obs) == N and obs[0].dtype == np.float64
+        assert isinstance(rew, list) and isinstance(rew[0], float) and isinstance(done, list) and isinstance(done[0], bool)
+        assert all(d == bool(g["done"][t]) for d in done)
+        assert np.abs(np.array(rew) - g["reward"][t]).max() <= 1e-5
+        assert np.abs(info["dist_travelled"] - g["dist"][t]).max() <= tol and info["dist_travelled"].dtype == np.float64
+        assert info.get("message") == MSG[int(g["viol"][t])]
+        assert info.get("remaining", -1) == int(g["remaining"][t])
+        if np.abs(np.array(obs) - g["obs"][t]).max() > tol:        # a float32 near-tie in the neighbour order
+            assert sorted(np.round(np.array(obs).ravel(), 4)) == pytest.approx(sorted(np.round(g["obs"][t].ravel(), 4)), abs=2e-4)
+        assert w.env.agent_poses.shape == (3, N)
+    w.close()
+
+
+def test_gymma_vec_env_contract():
+    import torch
+    from marbler_amd.gymma import GymmaVecEnv
+    E = 64
+    env = GymmaVecEnv("robotarium_gym:PredatorCapturePrey-v0", E, time_limit=30,
+                      overrides={"predator": 3, "capture": 2, "n_agents": 5})
+    info = env.get_env_info()
+    assert info == {"state_shape": 80, "obs_shape": 16, "n_actions": 5, "n_agents": 5, "episode_limit": 30}
+    obs, state = env.reset()
+    assert obs.shape == (E, 5, 16) and state.shape == (E, 80) and float(obs.abs().max()) == 0
+    assert env.get_avail_actions().shape == (E, 5, 5) and int(env.get_avail_actions().min()) == 1
+    g = torch.Generator(device=obs.device)
+    g.manual_seed(0)
+    ended_total = 0
+    el = torch.zeros(E, dtype=torch.int64, device=obs.device)
+    for t in range(70):
+        a = torch.randint(0, 5, (E, 5), generator=g, device=obs.device, dtype=torch.int32)
+        r, term, inf = env.step(a)
+        assert r.shape == (E,) and term.shape == (E,) and term.dtype == torch.bool
+        assert torch.allclose(r, env.env.reward.sum(1))                     # float(sum(reward_n))
+        el += 1
+        scen_done = env.env.done_u8.bool()
+        assert torch.equal(term, scen_done | (el >= 30))                    # gym TimeLimit on top of the scenario
+        assert torch.equal(inf["TimeLimit.truncated"], (el >= 30) & ~scen_done)
+        el[term] = 0
+        ended_total += int(term.sum())
+        # an ended env shows the reset observation (zeros) next; a running one its own position
+        o = env.get_obs()
+        assert float(o[term].abs().max() if term.any() else 0) == 0
+        run = ~term
+        assert torch.equal(o[run][:, :, 0], env.env.poses[run][:, 0])
+        assert torch.equal(env.get_state(), o.reshape(E, -1))
+    assert ended_total >= 2 * E
+    env.close()
+
+
+def test_gymma_single_env_types():
+    from marbler_amd.gymma import GymmaEnv
+    env = GymmaEnv("robotarium_gym:Warehouse-v0", time_limit=5)
+    obs, state = env.reset()
+    assert len(obs) == env.n_agents and state.shape == (env.get_state_size(),)
+    for t in range(5):
+        r, done, info = env.step([1] * env.n_agents)
+        assert isinstance(r, float) and isinstance(done, bool)
+    assert done and info.get("TimeLimit.truncated")
+    assert env.get_env_info()["n_actions"] == 5 and len(env.get_avail_actions()) == env.n_agents
+    env.close()

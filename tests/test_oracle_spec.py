@@ -118,7 +118,7 @@ def test_float32_tier_tracks_float64_tier(path, oracle_lib):
     assert angle_diff(a.poses[ok][:, 2], b.poses[ok][:, 2]).max() <= 5e-4
     assert np.abs(a.dist[ok] - b.dist[ok]).max() <= tol
     assert np.abs(a.reward[ok] - b.reward[ok]).max() <= 1e-5
-    for k in ("prey_sensed", "prey_captured", "loaded", "load", "zone_load", "messages"):
+    for k in ("prey_sensed", "prey_captured", "loaded", "load", "zone_load", "messages", "pixel_type", "reached_goal"):
         assert np.array_equal(getattr(a, k)[ok], getattr(b, k)[ok]), k
     bad = np.abs(a.obs[ok] - b.obs[ok]).max(axis=2) > tol
     assert bad.mean() < 0.01
