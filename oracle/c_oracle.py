@@ -84,7 +84,7 @@ def params_from_config(scenario, cfg, collision_variant="offset", dtype=np.float
     p.barrier_has_unsafe_gain = 1 if bc == "safe" else 0
     p.safety_radius = 0.2 if bc == "safe" else 0.17   # controller.py:13-16
     p.barrier_gain, p.unsafe_barrier_gain, p.barrier_magnitude_limit = 100.0, 1e6, 0.2
-    p.collision_variant = {"center": 0, "offset": 1}[collision_variant]
+    p.collision_variant = {"center": 0, "offset": 1}[cfg.get("collision_variant", collision_variant)]
     p.time_step = 0.033
     p.bound_x0, p.bound_y0, p.bound_w, p.bound_h = -1.6, -1.0, 3.2, 2.0
     p.robot_diameter, p.wheel_radius, p.max_linear_velocity = 0.11, 0.016, 0.2

@@ -17,6 +17,10 @@ CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5
          ("MaterialTransport", {}, 20, 100),
          ("PredatorCapturePrey", {"predator": 6, "capture": 6, "n_agents": 12, "num_prey": 10, "start_dist": 0.25,
                                   "num_neighbors": 4}, 5, 60),
+         ("PredatorCapturePrey", {"predator": 3, "capture": 2, "collision_variant": "center"}, 5, 150),
+         ("Warehouse", {"n_agents": 8, "barrier_certificate": "default"}, 5, 150),
+         ("PredatorCapturePrey", {"predator": 3, "capture": 2, "penalize_violations": False}, 5, 120),
+         ("MaterialTransport", {"capability_aware": True, "qp_max_sweeps": 6}, 20, 80),
          ("Simple", {}, 5, 130),
          ("Simple", {"n_agents": 6}, 5, 80),
          ("ArcticTransport", {}, 5, 200)]
