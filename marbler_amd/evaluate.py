@@ -1,0 +1,101 @@
+"""Batched greedy evaluation of EPyMARL actors on the device.
+
+The reference evaluates a trained model with `python -m robotarium_gym.main` -> `run_env`
+(utilities/misc.py:134-221): one env, one step at a time, actor forward on the CPU.  Here the
+same loop runs for E envs at once: observations never leave the GPU, the actor
+(utilities/rnn_agent.py:5-29 `RNNAgent`: fc1 -> ReLU -> GRUCell -> fc2, or the non-shared
+`RNNNSAgent` of rnn_ns_agent.py:5-36 with one such network per agent) is evaluated for all
+E x N agents with a handful of batched GEMMs (torch -> rocBLAS/hipBLASLt: plain library GEMMs),
+actions are the arg-max Q (misc.py:170), and the episode statistics accumulate in the env's
+on-device counters.  `load_actor` reads the reference's model zoo (`scenarios/*/models/*.th`
+state dicts + sacred `.json` configs, misc.py:65-91) unchanged.
+"""
+import json
+
+import torch
+
+
+class BatchedActor(object):
+    """RNNAgent / RNNNSAgent weights stacked as [A, ...] with A = 1 (shared) or N (one per agent)."""
+
+    def __init__(self, state_dict, n_agents, use_rnn=True, device="cpu"):
+        keys = list(state_dict.keys())
+        self.non_shared = keys[0].startswith("agents.")
+        self.use_rnn = bool(use_rnn)
+        self.n_agents = int(n_agents)
+
+        def stack(name):
+            if self.non_shared:
+                return torch.stack([state_dict[f"agents.{i}.{name}"] for i in range(self.n_agents)]).float().to(device)
+            return state_dict[name].float().unsqueeze(0).to(device)
+
+        self.w1, self.b1 = stack("fc1.weight"), stack("fc1.bias")          # [A,H,I], [A,H]
+        self.w2, self.b2 = stack("fc2.weight"), stack("fc2.bias")          # [A,O,H], [A,O]
+        if self.use_rnn:
+            self.wih, self.whh = stack("rnn.weight_ih"), stack("rnn.weight_hh")   # [A,3H,H]
+            self.bih, self.bhh = stack("rnn.bias_ih"), stack("rnn.bias_hh")
+        else:
+            self.wr, self.br = stack("rnn.weight"), stack("rnn.bias")
+        self.hidden_dim = self.w1.shape[1]
+        self.input_dim = self.w1.shape[2]
+        self.n_actions = self.w2.shape[1]
+
+    def init_hidden(self, num_envs):
+        return torch.zeros(num_envs, self.n_agents, self.hidden_dim, device=self.w1.device)
+
+    def _lin(self, x, w, b):
+        # x [E,N,I]; w [A,O,I]; b [A,O] -> [E,N,O]
+        if w.shape[0] == 1:
+            return torch.matmul(x, w[0].t()) + b[0]
+        return torch.einsum("eni,noi->eno", x, w) + b
+
+    def forward(self, inputs, hidden):
+        """inputs [E,N,input_dim], hidden [E,N,H] -> (q [E,N,n_actions], new hidden [E,N,H])."""
+        x = torch.relu(self._lin(inputs, self.w1, self.b1))
+        if self.use_rnn:   # torch.nn.GRUCell: r, z, n gates in that order
+            gi = self._lin(x, self.wih, self.bih)
+            gh = self._lin(hidden, self.whh, self.bhh)
+            H = self.hidden_dim
+            r = torch.sigmoid(gi[..., :H] + gh[..., :H])
+            z = torch.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
+            n = torch.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
+            h = (1.0 - z) * n + z * hidden
+        else:
+            h = torch.relu(self._lin(x, self.wr, self.br))
+        return self._lin(h, self.w2, self.b2), h
+
+
+def load_actor(model_file, model_config, n_agents, device="cuda:0"):
+    """model_file: a `.th` state dict of the reference's model zoo; model_config: its sacred `.json`
+    (path or dict).  Returns (BatchedActor, config dict) -- misc.py:65-91 without the env part."""
+    cfg = model_config if isinstance(model_config, dict) else json.load(open(model_config))
+    sd = torch.load(model_file, map_location="cpu")
+    return BatchedActor(sd, n_agents, use_rnn=cfg.get("use_rnn", True), device=device), cfg
+
+
+@torch.no_grad()
+def run_eval(env, actor, steps, obs_agent_id=True):
+    """Greedy rollout of `actor` on a VecRobotariumEnv (auto_reset on) for `steps` env steps.
+    Mirrors run_env's per-step body (misc.py:160-172): optional one-hot agent id appended to the
+    observation, actor forward, arg-max, env.step; hidden states restart at zero with each episode.
+    Returns the statistics run_env prints, from the env's on-device accumulators."""
+    E, N = env.E, env.N
+    dev = env.device
+    eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
+    obs = env.reset()
+    hidden = actor.init_hidden(E)
+    dist = torch.zeros(E, N, device=dev)
+    for _ in range(steps):
+        inp = torch.cat([obs, eye], dim=2) if obs_agent_id else obs
+        if inp.shape[2] != actor.input_dim:
+            raise ValueError(f"actor expects {actor.input_dim} inputs per agent, the env provides {inp.shape[2]}")
+        q, hidden = actor.forward(inp, hidden)
+        actions = q.argmax(dim=2).to(torch.int32)
+        obs, reward, done, info = env.step(actions)
+        dist += info["dist_travelled"]
+        hidden = torch.where(done[:, None, None], torch.zeros_like(hidden), hidden)
+        obs = torch.where(done[:, None, None], torch.zeros_like(obs), obs)   # the reference's reset() observation
+    ret_sum, episodes, ep_steps = env.episode_stats()
+    n = max(int(episodes), 1)
+    return {"episodes": int(episodes), "mean_return": float(ret_sum) / n, "mean_steps": float(ep_steps) / n,
+            "mean_dist_per_step": float(dist.sum()) / (steps * E * N)}
