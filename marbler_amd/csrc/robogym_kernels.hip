@@ -163,12 +163,14 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         emax[K - 1] = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
         mu[K - 1] = muA[K - 1] = muB[K - 1] = 0.0f;
     });
-    {   // "Threshold control inputs before QP"
-        const float nrm = norm2_spec(ux, uy);
-        const float sc = k.bml / nrm;
-        const bool clip = nrm > k.bml;
-        ux = clip ? ux * sc : ux;
-        uy = clip ? uy * sc : uy;
+    {   // "Threshold control inputs before QP": decided on squares; never taken after the 0.15 clip
+        const float n2u = ux * ux + uy * uy;
+        const bool clip = n2u > k.bml * k.bml;
+        if (__any(clip)) {
+            const float sc = k.bml / __builtin_sqrtf(n2u);
+            ux = clip ? ux * sc : ux;
+            uy = clip ? uy * sc : uy;
+        }
     }
     const float uhx = ux, uhy = uy;
     // A group drops out when converged (its lanes are exec-masked for the whole sweep body: groups
@@ -683,7 +685,14 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
             const float dtv = k.dt * v, dtw = k.dt * w;
             float sd, cd;
-            sincos_spec(dtw, sd, cd);
+            sincos_small_spec(dtw, sd, cd);
+            if (__any(__builtin_fabsf(dtw) > 0.25f)) {  // only with non-rps time steps / velocity limits
+                float sd2, cd2;
+                sincos_spec(dtw, sd2, cd2);
+                const bool big = __builtin_fabsf(dtw) > 0.25f;
+                sd = big ? sd2 : sd;
+                cd = big ? cd2 : cd;
+            }
             if (it0 == 0) RG_STAMP(1);  // first controller done
             int n_exec = n;             // sub-steps this env executes in this period
             bool died_now = false;
@@ -815,7 +824,51 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 }
             }
         };
-        if constexpr (!OBS_ONLY) {  // a11 _update_tracking_and_locations (PredatorCapturePrey.py:72-95)
+        float closest = -1.0f, qx = -5.0f, qy = -5.0f;
+        if (P <= 8) {
+            // common case (P = 6): the whole prey block in registers, one pass for tracking and
+            // the nearest-prey search, no second trip to LDS
+            float2 pl[8];
+            float d2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                pl[t] = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * (t < P ? t : P - 1)]);
+            }
+            uint32_t s_b = 0, c_b = 0;
+            const bool acts = lane_ok & (act == 4);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float dx = x - pl[t].x, dy = y - pl[t].y;
+                d2[t] = dx * dx + dy * dy;
+                const bool in = t < P;
+                s_b |= ((in & lane_ok & (d2[t] <= sr2)) ? 1u : 0u) << t;
+                c_b |= ((in & acts & (d2[t] <= cr2)) ? 1u : 0u) << t;
+            }
+            if constexpr (!OBS_ONLY) {  // a11 _update_tracking_and_locations (PredatorCapturePrey.py:72-95)
+                s_b = group_or<GW>(s_b);
+                c_b = group_or<GW>(c_b);
+                nsen_lo = sen_lo | (s_b & ~cap_lo);            // sensed: any agent in range, prey not yet captured
+                ncap_lo = cap_lo | (nsen_lo & c_b & ~cap_lo);  // captured: sensed and a 'no_action' agent in range
+                if (env_ok && ag < P) {
+                    a.st.prey_sensed[static_cast<size_t>(e) * P + ag] = (nsen_lo >> ag) & 1u;
+                    a.st.prey_captured[static_cast<size_t>(e) * P + ag] = (ncap_lo >> ag) & 1u;
+                }
+                if constexpr (GW < 8)
+                    if (env_ok && ag + GW < P) {
+                        a.st.prey_sensed[static_cast<size_t>(e) * P + ag + GW] = (nsen_lo >> (ag + GW)) & 1u;
+                        a.st.prey_captured[static_cast<size_t>(e) * P + ag + GW] = (ncap_lo >> (ag + GW)) & 1u;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {  // a13 nearest uncaptured prey within the agent's own sensing radius
+                const bool cap = ((ncap_lo >> t) & 1u) != 0;
+                const bool take = (t < P) & !cap & (d2[t] <= sr2) & ((d2[t] < closest) | (closest == -1.0f));
+                qx = take ? pl[t].x : qx;
+                qy = take ? pl[t].y : qy;
+                closest = take ? d2[t] : closest;
+            }
+        } else {
+        if constexpr (!OBS_ONLY) {  // a11, general P
             uint32_t s_lo = 0, s_hi = 0, c_lo = 0, c_hi = 0;  // prey this agent senses / could capture
             const bool acts = lane_ok & (act == 4);
             const int P32 = P < 32 ? P : 32;
@@ -825,8 +878,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             });
             s_lo = group_or<GW>(s_lo);
             c_lo = group_or<GW>(c_lo);
-            nsen_lo = sen_lo | (s_lo & ~cap_lo);          // sensed: any agent in range, prey not yet captured
-            ncap_lo = cap_lo | (nsen_lo & c_lo & ~cap_lo);  // captured: sensed and a 'no_action' agent in range
+            nsen_lo = sen_lo | (s_lo & ~cap_lo);
+            ncap_lo = cap_lo | (nsen_lo & c_lo & ~cap_lo);
             if (P > 32) {
                 scan(32, P, [&](int i, bool in, float, float, float d2) {
                     s_hi |= ((in & lane_ok & (d2 <= sr2)) ? 1u : 0u) << ((i - 32) & 31);
@@ -846,9 +899,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 }
             }
         }
-        // a13 own observation: nearest uncaptured prey within the agent's own sensing radius
-        float closest = -1.0f, qx = -5.0f, qy = -5.0f;
-        {
+        {   // a13, general P
             auto nearest = [&](uint32_t capmask, int base) {
                 return [&, capmask, base](int i, bool in, float px, float py, float d2) {
                     const bool cap = ((capmask >> ((i - base) & 31)) & 1u) != 0;
@@ -860,6 +911,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             };
             scan(0, P < 32 ? P : 32, nearest(ncap_lo, 0));
             if (P > 32) scan(32, P, nearest(ncap_hi, 32));
+        }
         }
         const int od = p.capability_aware ? 6 : 4;
         lds.own[lane][0] = x;

@@ -34,6 +34,17 @@ __device__ __forceinline__ void sincos_spec(float t, float &s, float &c) {
     c = cc;
 }
 
+// sin/cos of the per-sub-step heading increment dt*w (|.| <= 0.12 rad with the rps constants): Taylor
+// polynomials, no range reduction; valid for |t| <= 0.25 (the caller falls back to sincos_spec above)
+__device__ __forceinline__ void sincos_small_spec(float t, float &s, float &c) {
+    const float z = t * t;
+    const float sp = __builtin_fmaf(z, 8.33333377e-3f, -1.66666672e-1f);
+    s = __builtin_fmaf(t * z, sp, t);
+    float cp = __builtin_fmaf(z, -1.38888892e-3f, 4.16666679e-2f);
+    cp = __builtin_fmaf(z, cp, -0.5f);
+    c = __builtin_fmaf(z, cp, 1.0f);
+}
+
 // rps wraps headings with atan2(sin t, cos t): the identity on (-pi, pi].  The float spec
 // subtracts 2*pi (hi + lo) only when |t| exceeds pi (see oracle/oracle_core.h).
 __device__ __forceinline__ float wrap_spec(float t) {

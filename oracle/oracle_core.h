@@ -80,6 +80,22 @@ static inline float FN(wrap)(float t) {
     else if (t < -3.1415927410125732421875f) t = (t + 6.283185482025146484375f) + (-1.74845553146951715462e-07f);
     return t;
 }
+/* sin/cos of the per-sub-step heading increment dt*w (|dt*w| <= 0.033 * 3.64 = 0.12 rad with the rps
+ * constants): Taylor polynomials without range reduction (truncation < 1e-10 for |t| <= 0.25); larger
+ * arguments take the general routine. */
+static inline void FN(sincos_step)(float t, float *s, float *c) {
+    if (__builtin_fabsf(t) <= 0.25f) {
+        float z = t * t;
+        float sp = __builtin_fmaf(z, 8.33333377e-3f, -1.66666672e-1f);
+        *s = __builtin_fmaf(t * z, sp, t);
+        float cp = __builtin_fmaf(z, -1.38888892e-3f, 4.16666679e-2f);
+        cp = __builtin_fmaf(z, cp, -0.5f);
+        *c = __builtin_fmaf(z, cp, 1.0f);
+    } else {
+        FN(sincos)(t, s, c);
+    }
+}
+#define SINCOS_STEP(t, s, c) FN(sincos_step)((t), (s), (c))
 #define WRAP(t) FN(wrap)(t)
 #define SINCOS(t, s, c) FN(sincos)((t), (s), (c))
 #define ATAN2(y, x) FN(atan2)((y), (x))
@@ -173,9 +189,17 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
     /* "Threshold control inputs before QP" */
     REAL uhx[ORC_MAXN], uhy[ORC_MAXN];
     for (int a = 0; a < N; ++a) {
+#if ORC_IS_F32
+        /* float spec: the decision on squares (after the 0.15 position clip this branch is never
+         * taken with the rps constants, so the common path has no sqrt / divide) */
+        REAL n2u = ux[a] * ux[a] + uy[a] * uy[a];
+        if (n2u > R(p->barrier_magnitude_limit) * R(p->barrier_magnitude_limit)) {
+            REAL sc = R(p->barrier_magnitude_limit) / SQRT(n2u);
+#else
         REAL nrm = SQRT(ux[a] * ux[a] + uy[a] * uy[a]);
         if (nrm > R(p->barrier_magnitude_limit)) {
             REAL sc = R(p->barrier_magnitude_limit) / nrm;
+#endif
             ux[a] = ux[a] * sc;
             uy[a] = uy[a] * sc;
         }
@@ -432,7 +456,7 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
         for (int a = 0; a < N; ++a) {
             dtv[a] = dt * v[a];
             dtw[a] = dt * w[a];
-            SINCOS(dtw[a], &sd[a], &cd[a]);
+            SINCOS_STEP(dtw[a], &sd[a], &cd[a]);
         }
         int n_exec = n;
         for (int j = 0; j < n; ++j) {
@@ -830,6 +854,9 @@ int FN(orc_controller)(const orc_params *p, const REAL *poses /*3xN*/, const REA
 #undef SINCOS
 #undef ATAN2
 #undef WRAP
+#ifdef SINCOS_STEP
+#undef SINCOS_STEP
+#endif
 #undef SQRT
 #undef FMA
 #undef DIST

@@ -13,7 +13,8 @@ FLAT = ("goal_col",)
 
 
 def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Step fixtures (the actor_*.npz files are the policy-network vectors of tests/test_evaluate.py)."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith("actor_"))
 
 
 def load_golden(path):
