@@ -26,6 +26,24 @@ ALGO_BYTES_PER_ENV_STEP = 585
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def measured_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r1_final_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc runs).
+    Counters cannot be read from inside an un-profiled run; returns (bytes, source) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", "r1_final_pmc_summary.csv")
+    try:
+        import csv
+        kb = {}
+        for r in csv.DictReader(open(path)):
+            if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                kb[r["counter"]] = float(r["mean_per_launch"])
+        if len(kb) == 2:
+            return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, "profiles/r1_final_pmc_summary.csv"
+    except OSError:
+        pass
+    return None, None
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The reference-shaped NumPy port (oracle/np_port.py: one env per object, Python loop over
     the 29 sub-iterations, float64) on ONE host core, same scenario config, random policy.
@@ -162,6 +180,8 @@ def main():
         value = total_agent_steps / elapsed
         bytes_per_launch = ALGO_BYTES_PER_ENV_STEP * E if args.scenario == "PredatorCapturePrey" else None
         achieved = bytes_per_launch / (gpu_ms_total / K * 1e-3) / 1e9 if bytes_per_launch else None
+        traffic, traffic_src = measured_traffic() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU) \
+            else (None, None)
         out = {
             "metric": "env agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
@@ -170,7 +190,8 @@ def main():
                                    f"auto-reset, update_frequency {env.params.update_frequency}",
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "rg::step_kernel<PCP,GW=8>",
                          "kernel_ms_avg": gpu_ms_total / K,   # HIP events around the timed region / K (back-to-back launches)
                          "kernel_ms_avg_event_pair_per_launch": kernel_ms,
