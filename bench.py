@@ -151,8 +151,9 @@ def main():
     for i in range(K):
         rc = step(ptrs[(W + i) % n_batches])
     ev1.record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0          # this rank's K steps, device-complete
     barrier()
-    elapsed = time.perf_counter() - t0
     assert rc == 0
     gpu_ms_total = ev0.elapsed_time(ev1)
     if world > 1:
