@@ -57,5 +57,8 @@ struct KernelArgs {
 
 hipError_t launch_step(const KernelArgs &a, bool obs_only, hipStream_t stream);
 hipError_t launch_reset(const KernelArgs &a, hipStream_t stream);
+// thread-per-env step kernel (robogym_tpe.hip): same results, chosen by the host for large batches
+bool tpe_supported(const rg_scenario_params &p);
+hipError_t launch_step_tpe(const KernelArgs &a, hipStream_t stream);
 
 }  // namespace rg

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -21,7 +22,15 @@ struct rg_handle {
     int32_t device;
     hipStream_t stream;
     bool bound;
+    bool use_tpe;  // step with the thread-per-env kernel (robogym_tpe.hip) instead of the lane-group kernel
 };
+
+// Which step kernel: both give identical results.  The lane-group kernel has the shorter chain for
+// small batches; the thread-per-env kernel takes over once the batch fills the chip.  Measured
+// cross-over on MI355X (tools/perf_probe.py --set cross): N <= 5 at ~30k envs,
+// N = 6 at ~64k; for N >= 7 the per-lane register footprint (28 pairs) leaves one wave per SIMD and
+// the lane-group kernel stays ahead.  RG_STEP_KERNEL=group|tpe forces one (tests, profiling).
+static int32_t tpe_min_envs(int n_agents) { return n_agents <= 5 ? 32768 : n_agents == 6 ? 65536 : INT32_MAX; }
 
 static thread_local char g_err[512] = "";
 
@@ -108,6 +117,11 @@ rg_handle *rg_create(const rg_scenario_params *params, int32_t num_envs, int64_t
     h->device = device;
     h->stream = static_cast<hipStream_t>(hip_stream);
     h->bound = false;
+    h->use_tpe = rg::tpe_supported(*params) && num_envs >= tpe_min_envs(params->n_agents);
+    if (const char *force = getenv("RG_STEP_KERNEL")) {
+        if (!strcmp(force, "group")) h->use_tpe = false;
+        else if (!strcmp(force, "tpe") && rg::tpe_supported(*params)) h->use_tpe = true;
+    }
     return h;
 }
 
@@ -185,7 +199,7 @@ int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t 
     a.io = *io;
     a.auto_reset = auto_reset;
     a.seed = seed;
-    return launched(rg::launch_step(a, false, h->stream));
+    return launched(h->use_tpe ? rg::launch_step_tpe(a, h->stream) : rg::launch_step(a, false, h->stream));
 }
 
 int rg_get_obs(rg_handle *h, float *obs) {

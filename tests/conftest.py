@@ -19,6 +19,15 @@ def oracle_lib():
     return c_oracle
 
 
+@pytest.fixture(params=["group", "tpe"])
+def step_kernel(request, monkeypatch):
+    """Runs a GPU test once per step kernel (lane-group / thread-per-env; rg_create reads
+    RG_STEP_KERNEL).  Configurations the thread-per-env kernel does not cover (N > 8) run the
+    lane-group kernel in both instances."""
+    monkeypatch.setenv("RG_STEP_KERNEL", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_artifacts():
     """The suites need the two in-tree libraries: librobogym_hip.so (hipcc cross-compiles without a

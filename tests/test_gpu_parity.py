@@ -8,7 +8,7 @@ import pytest
 
 from helpers import angle_diff, golden_files, gpu_from_state, load_golden, oracle_from_state, pre_state
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("step_kernel")]
 
 
 def _run_gpu(scenario, cfg, state, actions):

@@ -7,7 +7,7 @@ import pytest
 
 from helpers import oracle_reset_params
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("step_kernel")]
 
 CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 260),
          ("PredatorCapturePrey", {"num_neighbors": 2, "capability_aware": True}, 5, 120),
@@ -162,3 +162,32 @@ def test_step_is_deterministic_and_shard_invariant():
         assert torch.equal(o, torch.cat([o1, o2])) and torch.equal(r, torch.cat([r1, r2])) and \
             torch.equal(d, torch.cat([d1, d2]))
     assert torch.equal(full.done_return_sum, torch.cat([lo.done_return_sum, hi.done_return_sum]))
+
+
+def test_large_batch_dispatch_matches_lane_group_kernel(monkeypatch):
+    """At 32768 envs the library picks the thread-per-env kernel on its own (robogym_capi.hip);
+    every output and the whole state must equal the lane-group kernel's, bit for bit, over steps
+    that include auto-resets."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    E, ov = 32768, {"predator": 3, "capture": 2, "n_agents": 5}
+    monkeypatch.delenv("RG_STEP_KERNEL", raising=False)
+    auto = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov, seed=5)
+    monkeypatch.setenv("RG_STEP_KERNEL", "group")
+    ref = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov, seed=5)
+    g = torch.Generator(device=auto.device)
+    g.manual_seed(2)
+    auto.reset()
+    ref.reset()
+    for t in range(40):
+        a = torch.randint(0, 5, (E, 5), generator=g, device=auto.device, dtype=torch.int32)
+        o1, r1, d1, i1 = auto.step(a)
+        o2, r2, d2, i2 = ref.step(a)
+        assert torch.equal(o1.view(torch.int32), o2.view(torch.int32))
+        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2)
+        for k in i1:
+            assert torch.equal(i1[k], i2[k]), k
+    s1, s2 = auto.state_dict(), ref.state_dict()
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    assert int(auto.done_count.sum()) > 0

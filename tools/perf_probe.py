@@ -58,5 +58,31 @@ if __name__ == "__main__":
             out.append(probe("PredatorCapturePrey", E, steps=200 if E < 100000 else 50))
         out.append(probe("Warehouse", 4096))
         out.append(probe("MaterialTransport", 4096, steps=200))
+    if args.set == "scale":   # both step kernels across batch sizes (RG_STEP_KERNEL is read at rg_create)
+        for kern in ("group", "tpe"):
+            os.environ["RG_STEP_KERNEL"] = kern
+            for scn, Es in (("PredatorCapturePrey", (256, 1024, 2048, 4096, 8192, 16384, 65536, 131072, 524288)),
+                            ("Warehouse", (4096, 65536)), ("MaterialTransport", (4096, 65536))):
+                for E in Es:
+                    r = probe(scn, E, steps=200 if E < 100000 else 50)
+                    r["kernel"] = kern
+                    out.append(r)
+                    print(json.dumps(r), flush=True)
+        out = []
+    if args.set == "cross":   # cross-over between the two step kernels per agent count
+        for kern in ("group", "tpe"):
+            os.environ["RG_STEP_KERNEL"] = kern
+            cases = [("PredatorCapturePrey", E, {}) for E in (24576, 32768, 49152)]
+            cases += [("PredatorCapturePrey", E, {"predator": 2, "capture": 2, "n_agents": 4}) for E in (32768, 131072, 524288)]
+            cases += [("PredatorCapturePrey", E, {"predator": 4, "capture": 3, "n_agents": 7}) for E in (32768, 131072, 524288)]
+            cases += [("Warehouse", E, {}) for E in (131072, 524288)]
+            cases += [("Warehouse", E, {"n_agents": 6}) for E in (32768, 131072)]
+            for scn, E, ov in cases:
+                r = probe(scn, E, steps=100 if E < 100000 else 30, **ov)
+                r["kernel"] = kern
+                # mean over waves of the per-64-env maximum of the step's sweep count (TPE divergence cost)
+                print(json.dumps(r), flush=True)
+    if args.set == "big":     # one saturated configuration (for rocprofv3 --pmc runs); RG_STEP_KERNEL picks the kernel
+        out.append(probe("PredatorCapturePrey", 524288, steps=20, warm=10))
     for r in out:
         print(json.dumps(r))
