@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librobogym_hip.so")
 SOURCES = ["robogym_kernels.hip", "robogym_tpe.hip", "robogym_capi.hip"]
-HEADERS = [os.path.join(CSRC, "sim_math.h"), os.path.join(CSRC, "kernel_args.h"),
+HEADERS = [os.path.join(CSRC, "sim_math.h"), os.path.join(CSRC, "kernel_args.h"), os.path.join(CSRC, "device_common.h"),
            os.path.join(HERE, "..", "include", "robogym.h")]
 ARCH = "gfx950"
 

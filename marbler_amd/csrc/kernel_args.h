@@ -1,6 +1,7 @@
 // kernel_args.h -- the one argument block of every launch (host <-> device contract).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/robogym.h"
@@ -13,8 +14,24 @@ namespace rg {
 struct Consts {
     float dt, pd, inv_pd, r2, wlim, vmax, wmax, pvl, bml;
     float xmin, xmax, ymin, ymax, coll_off, coll_lim2;
-    int32_t thr_q;  // collision pre-test threshold on the squared int16 distance (4 LSB margin)
+    float thr_pre;         // collision pre-test: threshold on the squared distance of the binary16-rounded points
+    float xc, xh, yc, yh;  // boundary pre-test: arena centre and half extents
 };
+
+// Conservative pre-tests of _validate (roboEnv.py:82-94).  The exact float tests run only when a
+// pre-test fires; a pre-test may fire needlessly but never misses:
+//  * collision: the collision points are rounded toward zero to binary16 pairs.  For |coordinate| <
+//    2^(m+1) m the spacing is 2^(m-10) m, so each rounded coordinate is off by less than that, their
+//    packed difference by less than twice that plus its own rounding (<= 2^-14 m below 0.25 m), and the
+//    distance by sqrt(2) times the per-axis error; `pre_margin` is that bound with 5 % on top.
+//  * boundary: a robot moves at most |dt v| (1 + 1e-6) per sub-step, so all pre-update positions of a
+//    chunk of C sub-steps lie within (C-1) |dt v| of the first; the test is |x - xc| + margin > xh.
+constexpr float PRE_SLACK = 2e-6f;  // roundings of the position updates and of xc / xh
+inline float pre_margin(float max_abs_coordinate) {
+    float spacing = 0.0009765625f;  // 2^-10: binary16 spacing in [1, 2)
+    for (float lim = 2.0f; lim <= max_abs_coordinate && lim < 1024.0f; lim *= 2.0f) spacing *= 2.0f;
+    return 1.05f * 1.41421356f * (2.0f * spacing + 6.103515625e-05f);
+}
 
 inline Consts make_consts(const rg_scenario_params &p) {
     Consts k;
@@ -35,10 +52,13 @@ inline Consts make_consts(const rg_scenario_params &p) {
     k.coll_off = off ? p.collision_offset : 0.0f;
     const float lim = off ? p.collision_diameter : p.robot_diameter;
     k.coll_lim2 = lim * lim;
-    // positions are quantised at 4 m <-> 32767 (LSB 0.122 mm); each end point is off by <= 1 LSB per
-    // axis, so the distance by < 3 LSB: 4 LSB of margin keep the integer test conservative
-    const float lq = lim * 8191.75f + 4.0f;
-    k.thr_q = static_cast<int32_t>(lq * lq) + 1;
+    const float ax = fmaxf(fabsf(k.xmin), fabsf(k.xmax)), ay = fmaxf(fabsf(k.ymin), fabsf(k.ymax));
+    const float lp = lim + pre_margin(fmaxf(ax, ay) + 0.25f);  // robots that left the arena fire the boundary test
+    k.thr_pre = lp * lp * 1.00001f;
+    k.xc = 0.5f * (k.xmin + k.xmax);
+    k.xh = 0.5f * (k.xmax - k.xmin);
+    k.yc = 0.5f * (k.ymin + k.ymax);
+    k.yh = 0.5f * (k.ymax - k.ymin);
     return k;
 }
 

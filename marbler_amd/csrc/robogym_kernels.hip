@@ -25,98 +25,16 @@
 
 #include <type_traits>
 
-#include "../../include/robogym.h"
-#include "kernel_args.h"
-#include "sim_math.h"
+#include "device_common.h"
 
 namespace rg {
 
-constexpr int WAVE = 64;
 #ifndef RG_CHUNK
-#define RG_CHUNK 4
+#define RG_CHUNK 5
 #endif
-constexpr int CHUNK = RG_CHUNK;  // sub-steps validated together (ILP across independent test chains); 8 measured no faster
-constexpr int MAX_DRAWS = 128;  // u32 draws per reset: 4 + 2N + P <= 4 + 32 + 64, rounded up to blocks
-
-// ------------------------------------------------------------------ lane exchange (DPP)
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
-}
-// value held by lane (lane ^ K), K in 1..15, within a 16-lane row
-template <int K>
-__device__ __forceinline__ int xor_lane_i(int v) {
-    static_assert(K >= 1 && K <= 15, "xor distance");
-    constexpr int QP1 = 0xB1, QP2 = 0x4E, QP3 = 0x1B;  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
-    constexpr int HALF_MIRROR = 0x141, MIRROR = 0x140, ROR8 = 0x128;
-    if constexpr (K == 1) return dpp_i<QP1>(v);
-    else if constexpr (K == 2) return dpp_i<QP2>(v);
-    else if constexpr (K == 3) return dpp_i<QP3>(v);
-    else if constexpr (K == 7) return dpp_i<HALF_MIRROR>(v);
-    else if constexpr (K == 4) return dpp_i<QP3>(dpp_i<HALF_MIRROR>(v));
-    else if constexpr (K == 5) return dpp_i<QP2>(dpp_i<HALF_MIRROR>(v));
-    else if constexpr (K == 6) return dpp_i<QP1>(dpp_i<HALF_MIRROR>(v));
-    else if constexpr (K == 15) return dpp_i<MIRROR>(v);
-    else if constexpr (K == 8) return dpp_i<ROR8>(v);
-    else if constexpr (K == 9) return dpp_i<QP1>(dpp_i<ROR8>(v));
-    else if constexpr (K == 10) return dpp_i<QP2>(dpp_i<ROR8>(v));
-    else if constexpr (K == 11) return dpp_i<QP3>(dpp_i<ROR8>(v));
-    else if constexpr (K == 12) return dpp_i<QP3>(dpp_i<MIRROR>(v));
-    else if constexpr (K == 13) return dpp_i<QP2>(dpp_i<MIRROR>(v));
-    else return dpp_i<QP1>(dpp_i<MIRROR>(v));
-}
-template <int K>
-__device__ __forceinline__ float xor_lane(float v) {
-    return __builtin_bit_cast(float, xor_lane_i<K>(__builtin_bit_cast(int, v)));
-}
-
-typedef short short2v __attribute__((ext_vector_type(2)));
-
-template <int I, int END, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < END) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, END>(f);
-    }
-}
-
-// reductions over the lanes of a group: butterflies whose every stage is ONE DPP permute
-// (xor 1, xor 2, then the half-row / row mirrors)
-template <int GW>
-__device__ __forceinline__ float group_max(float v) {
-    v = fmaxf(v, xor_lane<1>(v));
-    v = fmaxf(v, xor_lane<2>(v));
-    if constexpr (GW >= 8) v = fmaxf(v, xor_lane<7>(v));
-    if constexpr (GW >= 16) v = fmaxf(v, xor_lane<15>(v));
-    return v;
-}
-// the same for NON-NEGATIVE floats, on their bit patterns (order-preserving; lets the DPP permute
-// fuse into v_max_u32 and needs no NaN canonicalisation)
-template <int GW>
-__device__ __forceinline__ float group_max_nonneg(float f) {
-    uint32_t v = __builtin_bit_cast(uint32_t, f);
-    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
-    v = mx(v, static_cast<uint32_t>(xor_lane_i<1>(static_cast<int>(v))));
-    v = mx(v, static_cast<uint32_t>(xor_lane_i<2>(static_cast<int>(v))));
-    if constexpr (GW >= 8) v = mx(v, static_cast<uint32_t>(xor_lane_i<7>(static_cast<int>(v))));
-    if constexpr (GW >= 16) v = mx(v, static_cast<uint32_t>(xor_lane_i<15>(static_cast<int>(v))));
-    return __builtin_bit_cast(float, v);
-}
-template <int GW>
-__device__ __forceinline__ uint32_t group_or(uint32_t v) {
-    v |= static_cast<uint32_t>(xor_lane_i<1>(static_cast<int>(v)));
-    v |= static_cast<uint32_t>(xor_lane_i<2>(static_cast<int>(v)));
-    if constexpr (GW >= 8) v |= static_cast<uint32_t>(xor_lane_i<7>(static_cast<int>(v)));
-    if constexpr (GW >= 16) v |= static_cast<uint32_t>(xor_lane_i<15>(static_cast<int>(v)));
-    return v;
-}
-// does any lane of my group have `pred` set?  (rare paths only: one ballot, then bit tests)
-template <int GW>
-__device__ __forceinline__ bool group_any(bool pred, int gbase) {
-    const unsigned long long m = __ballot(pred);
-    constexpr unsigned long long GM = (GW == 64) ? ~0ull : ((1ull << GW) - 1ull);
-    return ((m >> gbase) & GM) != 0ull;
-}
+// sub-steps validated together (ILP across independent test chains).  The controller periods of the
+// reference's configurations are 15 and 14 sub-steps: three chunks of 5, or two and a remainder chunk of 4.
+constexpr int CHUNK = RG_CHUNK;
 
 // ------------------------------------------------------------------ controller (a3..a8)
 // utilities/controller.py:20-24 over the restated rps closures,
@@ -246,187 +164,6 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     v = upd ? vv : v;
     w = upd ? ww : w;
     return my_sweeps;
-}
-
-// ------------------------------------------------------------------ LDS scratch (one wavefront)
-template <int GW>
-struct alignas(16) Lds {
-    float prey[WAVE / GW][RG_MAX_PREY * 2];  // the env's prey block (PredatorCapturePrey)
-    float own[WAVE][8];                      // each agent's own-observation row (<= 6 floats)
-    float ax[WAVE], ay[WAVE];                // MaterialTransport sequential replay / reward sum
-    int aload[WAVE];
-    uint8_t grid[WAVE / GW][RG_ARCTIC_ROWS * RG_ARCTIC_COLS];  // ArcticTransport terrain of the env
-    uint32_t draws[WAVE / GW][MAX_DRAWS];    // reset: Philox output
-    uint8_t perm[WAVE / GW][2][64];          // reset: Fisher-Yates permutations of the grid cells (agents, prey)
-    uint8_t sel[WAVE / GW][2][64];           // reset: chosen cells
-};
-
-// ------------------------------------------------------------------ reset sampler (a17)
-// misc.py:49-63 -> rps generate_initial_conditions (Appendix A.7): N distinct cells of an
-// nx x ny grid, then the scenario's shift.  The reference draws from NumPy's global MT19937;
-// here every (global env, episode) pair owns a Philox4x32-10 stream (DESIGN.md "reset").  Draw
-// order: [MaterialTransport: 4 for the two zone loads] N cells, N headings, [PCP: P prey cells].
-// The whole wave calls this (wave-uniform); groups with do_reset set take part: Philox blocks
-// and the permutation fill are spread over the group's lanes, the short Fisher-Yates chain runs
-// on the group's lane 0, and every lane writes its own agent's state.
-__device__ __forceinline__ float uniform01(uint32_t r) { return static_cast<float>(r >> 8) * 5.9604644775390625e-08f; }
-
-__device__ __forceinline__ int normal_int(uint32_t r1, uint32_t r2, float mean, float stdv) {
-    // int(np.random.normal(mean, std)) by Box-Muller on the spec'd log / sincos
-    const float u1 = static_cast<float>((r1 >> 8) + 1u) * 5.9604644775390625e-08f;  // (0, 1]
-    const float u2 = uniform01(r2);
-    const float rad = __builtin_sqrtf(-2.0f * log_spec(u1));
-    float sn, cs;
-    sincos_spec(u2 * 6.283185482025146484375f - 3.1415927410125732421875f, sn, cs);
-    return static_cast<int>(mean + stdv * (rad * cs));
-}
-
-// Partial Fisher-Yates over the grid cells.  The agents' draw and (PredatorCapturePrey) the prey's
-// draw are independent chains, so they run side by side on lanes 0 and 1 of the group, each on its
-// own permutation array (same instructions, different data).
-template <int GW>
-__device__ __forceinline__ void fisher_yates2(Lds<GW> &lds, int g, int ag, bool do_reset, const rg_grid &grid_a,
-                                              int count_a, int first_a, const rg_grid &grid_b, int count_b,
-                                              int first_b) {
-    const int Ca = grid_a.nx * grid_a.ny, Cb = count_b > 0 ? grid_b.nx * grid_b.ny : 0;
-    if (do_reset) {
-        for (int i = ag; i < Ca; i += GW) lds.perm[g][0][i] = static_cast<uint8_t>(i);
-        for (int i = ag; i < Cb; i += GW) lds.perm[g][1][i] = static_cast<uint8_t>(i);
-    }
-    __syncthreads();
-    if (do_reset && ag < 2) {
-        const int which = ag;
-        const int C = which ? Cb : Ca, count = which ? count_b : count_a, first = which ? first_b : first_a;
-        for (int i = 0; i < count; ++i) {
-            const uint32_t r = lds.draws[g][first + i];
-            const int j = i + static_cast<int>((static_cast<uint64_t>(r) * static_cast<uint32_t>(C - i)) >> 32);
-            const uint8_t t = lds.perm[g][which][i];
-            const uint8_t pj = lds.perm[g][which][j];
-            lds.perm[g][which][j] = t;
-            lds.perm[g][which][i] = pj;
-            lds.sel[g][which][i] = pj;
-        }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void cell_xy(const rg_grid &grid, int cell, float &x, float &y) {
-    const int cx = cell / grid.ny, cy = cell - cx * grid.ny;
-    const float fx = static_cast<float>(cx) * grid.spacing - grid.w2;
-    const float fy = static_cast<float>(cy) * grid.spacing - grid.h2;
-    x = (fx + grid.ox1) + grid.ox2;
-    y = (fy + grid.oy1) + grid.oy2;
-}
-
-template <int SCN, int GW>
-__device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, int e, int g, int ag, bool do_reset) {
-    const rg_scenario_params &p = a.p;
-    const int N = p.n_agents;
-    if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
-        // ArcticTransport.py:56-82: fixed start poses; terrain grid uniform in {0,1,2} (draws 0..95,
-        // row-major), goal column uniform in 1..11 (draw 96), goal block 2x2 in rows 0-1, row 7
-        // columns 1..10 cleared.  (The reference draws the column from Python's `random`.)
-        constexpr int CELLS = RG_ARCTIC_ROWS * RG_ARCTIC_COLS;
-        int32_t episode = 0;
-        if (do_reset) {
-            episode = a.st.reset_count[e];
-            const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
-            for (int b = ag; 4 * b < CELLS + 1; b += GW) {
-                uint32_t blk[4];
-                philox4x32_10(static_cast<uint32_t>(ge), static_cast<uint32_t>(ge >> 32),
-                              static_cast<uint32_t>(episode), static_cast<uint32_t>(b),
-                              static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32), blk);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) lds.draws[g][4 * b + t] = blk[t];
-            }
-        }
-        __syncthreads();
-        if (do_reset) {
-            const int gc = 1 + static_cast<int>((static_cast<uint64_t>(lds.draws[g][CELLS]) * 11u) >> 32);
-            for (int i = ag; i < CELLS; i += GW) {
-                const int row = i / RG_ARCTIC_COLS, col = i - row * RG_ARCTIC_COLS;
-                int val = static_cast<int>((static_cast<uint64_t>(lds.draws[g][i]) * 3u) >> 32);
-                if (row <= 1 && (col == gc || col == gc - 1)) val = 3;
-                if (row == 7 && col >= 1 && col <= 10) val = 0;
-                a.st.grid[static_cast<size_t>(e) * CELLS + i] = static_cast<uint8_t>(val);
-            }
-            if (ag < N) {
-                float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
-                X[ag] = ag == 0 ? -0.3f : ag == 1 ? 0.3f : ag == 2 ? -0.9f : 0.9f;  // ArcticTransport.py:30-33
-                X[N + ag] = -0.8f;
-                X[2 * N + ag] = 1.57079637050628662109375f;
-                a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
-                a.st.pixel_type[static_cast<size_t>(e) * N + ag] = 0;
-                a.st.reached_goal[static_cast<size_t>(e) * N + ag] = 0;
-            }
-            if (ag == 0) {
-                a.st.goal_col[e] = gc;
-                a.st.reset_count[e] = episode + 1;
-                a.st.episode_steps[e] = 0;
-            }
-        }
-        return;
-    }
-    constexpr bool HAS_PREY = (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) || (SCN == RG_SCN_SIMPLE);
-    const int P = HAS_PREY ? p.num_prey : 0;  // Simple: its single goal is drawn like one prey
-    constexpr int ZD = (SCN == RG_SCN_MATERIAL_TRANSPORT) ? 4 : 0;
-    const int ndraws = ZD + 2 * N + P;
-    int32_t episode = 0;
-    if (do_reset) {
-        episode = a.st.reset_count[e];
-        const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
-        for (int b = ag; 4 * b < ndraws; b += GW) {
-            uint32_t blk[4];
-            philox4x32_10(static_cast<uint32_t>(ge), static_cast<uint32_t>(ge >> 32), static_cast<uint32_t>(episode),
-                          static_cast<uint32_t>(b), static_cast<uint32_t>(a.seed), static_cast<uint32_t>(a.seed >> 32),
-                          blk);
-            lds.draws[g][4 * b + 0] = blk[0];
-            lds.draws[g][4 * b + 1] = blk[1];
-            lds.draws[g][4 * b + 2] = blk[2];
-            lds.draws[g][4 * b + 3] = blk[3];
-        }
-    }
-    fisher_yates2<GW>(lds, g, ag, do_reset, p.agent_grid, N, ZD, p.prey_grid, P, ZD + 2 * N);  // syncs inside
-    if (do_reset && ag < N) {
-        float x, y;
-        cell_xy(p.agent_grid, lds.sel[g][0][ag], x, y);
-        const float th = uniform01(lds.draws[g][ZD + N + ag]) * 6.283185482025146484375f - 3.1415927410125732421875f;
-        float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
-        X[ag] = x;
-        X[N + ag] = y;
-        X[2 * N + ag] = p.keep_theta ? th : 0.0f;
-        a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
-        if constexpr (SCN == RG_SCN_WAREHOUSE) a.st.loaded[static_cast<size_t>(e) * N + ag] = 0;
-        if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
-            a.st.load[static_cast<size_t>(e) * N + ag] = 0;
-            if (ag < 4) a.st.messages[4 * e + ag] = 0;
-        }
-    }
-    if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {  // MaterialTransport.py:99-100
-        if (do_reset && ag < 2) {
-            const float mean = ag == 0 ? p.zone1_mean : p.zone2_mean, sd = ag == 0 ? p.zone1_std : p.zone2_std;
-            a.st.zone_load[2 * e + ag] = normal_int(lds.draws[g][2 * ag], lds.draws[g][2 * ag + 1], mean, sd);
-        }
-    }
-    if constexpr (HAS_PREY) {
-        if (do_reset) {
-            for (int i = ag; i < P; i += GW) {
-                float x, y;
-                cell_xy(p.prey_grid, lds.sel[g][1][i], x, y);
-                float *pl = a.st.prey_loc + (static_cast<size_t>(e) * P + i) * 2;
-                pl[0] = x;
-                pl[1] = y;
-                if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-                    a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
-                    a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
-                }
-            }
-        }
-    }
-    if (do_reset && ag == 0) {
-        a.st.reset_count[e] = episode + 1;
-        a.st.episode_steps[e] = 0;
-    }
 }
 
 // ------------------------------------------------------------------ neighbour observations
@@ -664,14 +401,14 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         // advance once per period by fma; inside the period only x, y and (cos, sin) move.
         //
         // _validate every sub-step: the exact test (GW-1 DPP rounds of float math) runs only in a
-        // rare wave-uniform branch.  The common path is a conservative integer pre-test on the
-        // collision points quantised to int16 pairs (4 m <-> 32767, LSB 0.12 mm): per pair round one
-        // DPP + v_pk_sub_i16 + v_dot2, with a 4 LSB margin on the distance so it can never miss a
-        // collision the float test would flag.  Absent lanes / finished envs sit on far-apart ghost
-        // points.  CHUNK sub-steps are advanced and tested together: their test chains are
-        // independent, which is the only ILP a single wavefront has here.
-        const int thr_q = k.thr_q;
-        const int ghost_q = (32767 & 0xFFFF) | (((-28000 + 3500 * ag) & 0xFFFF) << 16);  // >= 0.43 m apart, > 2 m off
+        // rare wave-uniform branch.  The common path is a conservative pre-test (kernel_args.h): the
+        // collision points rounded to binary16 pairs -- per pair round one DPP + v_pk_add_f16 +
+        // v_dot2_f32_f16 -- against a threshold widened by the rounding bound, and one boundary test
+        // per chunk on the chunk's first position widened by the chunk's travel.  Absent lanes /
+        // finished envs sit on far-apart ghost points.  CHUNK sub-steps are advanced and tested
+        // together: their test chains are independent, which is the only ILP a single wavefront has here.
+        const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
+        const int ghost_q = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(1000.0f + 32.0f * ag, -1000.0f));
         float v = 0.0f, w = 0.0f, s = 0.0f, c = 1.0f;
         float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
         bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
@@ -694,6 +431,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 cd = big ? cd2 : cd;
             }
             if (it0 == 0) RG_STAMP(1);  // first controller done
+            const float mrg = __builtin_fmaf((CHUNK - 1) * 1.000001f, __builtin_fabsf(dtv), PRE_SLACK);
             int n_exec = n;             // sub-steps this env executes in this period
             bool died_now = false;
 
@@ -703,17 +441,12 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 const float x0 = x, y0 = y, c0 = c, s0 = s;
                 const bool live = lane_ok & !dead;
                 int q[C];
-                float bx_lo = x, bx_hi = x, by_lo = y, by_hi = y;  // extent of the pre-update positions
+                // every pre-update position of the chunk lies within (C-1)|dt v| of the first
+                const bool bnd_any = live & ((__builtin_fabsf(x - k.xc) + mrg > k.xh) | (__builtin_fabsf(y - k.yc) + mrg > k.yh));
                 static_for<0, C>([&](auto UU) {
                     constexpr int u = decltype(UU)::value;
-                    if constexpr (u > 0) {
-                        bx_lo = fminf(bx_lo, x);
-                        bx_hi = fmaxf(bx_hi, x);
-                        by_lo = fminf(by_lo, y);
-                        by_hi = fmaxf(by_hi, y);
-                    }
                     const float fx = __builtin_fmaf(k.coll_off, c, x), fy = __builtin_fmaf(k.coll_off, s, y);
-                    const int qr = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pknorm_i16(fx * 0.25f, fy * 0.25f));
+                    const int qr = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(fx, fy));
                     q[u] = live ? qr : ghost_q;
                     // Euler step (Appendix A.4); rotate (cos, sin) by dt*w
                     x = __builtin_fmaf(c, dtv, x);
@@ -728,15 +461,12 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                     constexpr int u = decltype(UU)::value;
                     static_for<1, GW>([&](auto KK) {
                         constexpr int K = decltype(KK)::value;
-                        const short2v dq = __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, q[u]),
-                                                                         __builtin_bit_cast(short2v, xor_lane_i<K>(q[u])));
-                        int d2;
-                        asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2) : "v"(dq));
+                        const half2v dq = __builtin_bit_cast(half2v, q[u]) - __builtin_bit_cast(half2v, xor_lane_i<K>(q[u]));
+                        const int d2 = dot2_bits(dq);
                         dmin = d2 < dmin ? d2 : dmin;
                     });
                 });
-                const bool bnd_any = live & ((bx_lo < k.xmin) | (bx_hi > k.xmax) | (by_lo < k.ymin) | (by_hi > k.ymax));
-                if (penalize && __any((dmin <= thr_q) | bnd_any)) {
+                if (penalize && __any((dmin <= thr_pre) | bnd_any)) {
                     // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
                     float rx = x0, ry = y0, rc = c0, rs = s0;
                     for (int u = 0; u < C; ++u) {
@@ -769,7 +499,9 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             };
             int j = 0;
             for (; j + CHUNK <= n; j += CHUNK) run_chunk(std::integral_constant<int, CHUNK>{}, j);
-            for (; j < n; ++j) run_chunk(std::integral_constant<int, 1>{}, j);
+            static_for<1, CHUNK>([&](auto RR) {  // the remainder as one shorter chunk
+                if (n - j == decltype(RR)::value) run_chunk(RR, j);
+            });
 
             // period end: heading and distance for the sub-steps this env executed
             const bool upd = env_ok & (!dead | died_now);

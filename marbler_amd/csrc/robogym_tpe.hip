@@ -21,17 +21,12 @@
 
 #include <type_traits>
 
-#include "../../include/robogym.h"
-#include "kernel_args.h"
-#include "sim_math.h"
+#include "device_common.h"
 
 namespace rg {
 namespace tpe {
 
-constexpr int WAVE = 64;
-constexpr int CH = 4;  // sub-steps per validated chunk
-
-typedef short short2v __attribute__((ext_vector_type(2)));
+constexpr int CH = 5;  // sub-steps per validated chunk (controller periods of 15 and 14 sub-steps: 5+5+5, 5+5+4)
 
 template <int I, int END, typename F>
 __device__ __forceinline__ void sfor(F &&f) {
@@ -196,114 +191,6 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     return sweeps;
 }
 
-// ------------------------------------------------------------------ reset sampler (a17), one lane per env
-// Same draws, same order, same arithmetic as reset_group of robogym_kernels.hip.
-struct Draws {
-    uint32_t k0, k1, c0, c1, c2;
-    uint32_t blk[4];
-    uint32_t cur, next;
-    __device__ __forceinline__ uint32_t u32() {
-        const uint32_t b = next >> 2;
-        if (b != cur) {
-            philox4x32_10(c0, c1, c2, b, k0, k1, blk);
-            cur = b;
-        }
-        const uint32_t ln = next & 3u;
-        ++next;
-        return ln == 0 ? blk[0] : ln == 1 ? blk[1] : ln == 2 ? blk[2] : blk[3];
-    }
-};
-__device__ __forceinline__ float uniform01(uint32_t r) { return static_cast<float>(r >> 8) * 5.9604644775390625e-08f; }
-
-__device__ inline int normal_int(Draws &d, float mean, float stdv) {
-    const uint32_t r1 = d.u32(), r2 = d.u32();
-    const float u1 = static_cast<float>((r1 >> 8) + 1u) * 5.9604644775390625e-08f;
-    const float u2 = uniform01(r2);
-    const float rad = __builtin_sqrtf(-2.0f * log_spec(u1));
-    float sn, cs;
-    sincos_spec(u2 * 6.283185482025146484375f - 3.1415927410125732421875f, sn, cs);
-    return static_cast<int>(mean + stdv * (rad * cs));
-}
-
-__device__ inline void sample_cells(Draws &d, const rg_grid &g, int count, uint8_t *perm, float *outx, float *outy,
-                                    int stride) {
-    const int C = g.nx * g.ny;
-    for (int i = 0; i < C; ++i) perm[i] = static_cast<uint8_t>(i);
-    for (int i = 0; i < count; ++i) {
-        const uint32_t r = d.u32();
-        const int j = i + static_cast<int>((static_cast<uint64_t>(r) * static_cast<uint32_t>(C - i)) >> 32);
-        const uint8_t t = perm[i];
-        perm[i] = perm[j];
-        perm[j] = t;
-        const int cell = perm[i];
-        const int cx = cell / g.ny, cy = cell - cx * g.ny;
-        const float x = static_cast<float>(cx) * g.spacing - g.w2;
-        const float y = static_cast<float>(cy) * g.spacing - g.h2;
-        outx[i * stride] = (x + g.ox1) + g.ox2;
-        outy[i * stride] = (y + g.oy1) + g.oy2;
-    }
-}
-
-template <int SCN>
-__device__ inline void reset_env(const KernelArgs &a, int e, uint8_t *perm) {
-    const rg_scenario_params &p = a.p;
-    const int N = p.n_agents;
-    const int32_t episode = a.st.reset_count[e];
-    a.st.reset_count[e] = episode + 1;
-    a.st.episode_steps[e] = 0;
-    const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
-    Draws d;
-    d.k0 = static_cast<uint32_t>(a.seed);
-    d.k1 = static_cast<uint32_t>(a.seed >> 32);
-    d.c0 = static_cast<uint32_t>(ge);
-    d.c1 = static_cast<uint32_t>(ge >> 32);
-    d.c2 = static_cast<uint32_t>(episode);
-    d.cur = 0xFFFFFFFFu;
-    d.next = 0;
-    float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
-    if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
-        constexpr int CELLS = RG_ARCTIC_ROWS * RG_ARCTIC_COLS;
-        uint8_t *grid = a.st.grid + static_cast<size_t>(e) * CELLS;
-        for (int i = 0; i < CELLS; ++i) grid[i] = static_cast<uint8_t>((static_cast<uint64_t>(d.u32()) * 3u) >> 32);
-        const int gc = 1 + static_cast<int>((static_cast<uint64_t>(d.u32()) * 11u) >> 32);
-        grid[gc] = grid[gc - 1] = grid[RG_ARCTIC_COLS + gc] = grid[RG_ARCTIC_COLS + gc - 1] = 3;
-        for (int col = 1; col <= 10; ++col) grid[7 * RG_ARCTIC_COLS + col] = 0;
-        a.st.goal_col[e] = gc;
-        for (int i = 0; i < 4; ++i) {
-            X[i] = i == 0 ? -0.3f : i == 1 ? 0.3f : i == 2 ? -0.9f : 0.9f;
-            X[4 + i] = -0.8f;
-            X[8 + i] = 1.57079637050628662109375f;
-            a.st.carry_dist[static_cast<size_t>(e) * 4 + i] = 0.0f;
-            a.st.pixel_type[static_cast<size_t>(e) * 4 + i] = 0;
-            a.st.reached_goal[static_cast<size_t>(e) * 4 + i] = 0;
-        }
-        return;
-    }
-    if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
-        a.st.zone_load[2 * e + 0] = normal_int(d, p.zone1_mean, p.zone1_std);
-        a.st.zone_load[2 * e + 1] = normal_int(d, p.zone2_mean, p.zone2_std);
-        for (int i = 0; i < 4; ++i) a.st.messages[4 * e + i] = 0;
-    }
-    sample_cells(d, p.agent_grid, N, perm, X, X + N, 1);
-    for (int i = 0; i < N; ++i) {
-        const float th = uniform01(d.u32()) * 6.283185482025146484375f - 3.1415927410125732421875f;
-        X[2 * N + i] = p.keep_theta ? th : 0.0f;
-        a.st.carry_dist[static_cast<size_t>(e) * N + i] = 0.0f;
-        if constexpr (SCN == RG_SCN_WAREHOUSE) a.st.loaded[static_cast<size_t>(e) * N + i] = 0;
-        if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) a.st.load[static_cast<size_t>(e) * N + i] = 0;
-    }
-    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY || SCN == RG_SCN_SIMPLE) {
-        const int P = p.num_prey;
-        float *pl = a.st.prey_loc + static_cast<size_t>(e) * P * 2;
-        sample_cells(d, p.prey_grid, P, perm, pl, pl + 1, 2);
-        if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY)
-            for (int i = 0; i < P; ++i) {
-                a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
-                a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
-            }
-    }
-}
-
 // ------------------------------------------------------------------ neighbour rows
 // obs slots 1..K of agent A from the own-observation rows of the K nearest others (ascending
 // squared distance, ties -> lower index); K >= N-1: all others in index order.
@@ -361,14 +248,12 @@ __device__ __forceinline__ void write_obs_with_neighbours(const float (&x)[N], c
     });
 }
 
-// ------------------------------------------------------------------ the step kernel
+// ------------------------------------------------------------------ one env step on one lane
+// returns whether the episode ended (roboEnv.py:38-96 + the scenario's step())
 template <int SCN, int N>
-__global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
-    __shared__ uint8_t perm_lds[WAVE][64];
+__device__ __forceinline__ bool step_env(const KernelArgs &a, const int e) {
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
-    const int e = blockIdx.x * WAVE + threadIdx.x;
-    if (e >= a.E) return;
     const size_t eN = static_cast<size_t>(e) * N;
 
     // ---- loads
@@ -425,9 +310,12 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
 
     // ---- a2 roboEnv.step, one controller period at a time (float spec of oracle/oracle_core.h)
     int viol = 0, max_sweeps = 0;
+#ifdef RG_TPE_DIAG
+    int diag = 0, diag_chunk = 0;
+#endif
     const bool penalize = p.penalize_violations != 0;
     const int U = p.update_frequency, period = p.controller_period;
-    const int thr_q = k.thr_q;
+    const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
     float v[N], w[N], s[N], c[N];
     for (int it0 = 0; it0 < U && !viol; it0 += period) {
         const int n = (U - it0) < period ? (U - it0) : period;
@@ -435,11 +323,15 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         for (int i = 0; i < N; ++i) sincos_spec(th[i], s[i], c[i]);
         const int sw = controller<N>(p, k, x, y, c, s, gx, gy, v, w);
         max_sweeps = sw > max_sweeps ? sw : max_sweeps;
-        float dtv[N], dtw[N], sd[N], cd[N];
+#ifdef RG_TPE_DIAG
+        diag |= sw << (it0 == 0 ? 8 : 0);
+#endif
+        float dtv[N], dtw[N], sd[N], cd[N], mrg[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             dtv[i] = k.dt * v[i];
             dtw[i] = k.dt * w[i];
+            mrg[i] = __builtin_fmaf((CH - 1) * 1.000001f, __builtin_fabsf(dtv[i]), PRE_SLACK);
             if (__builtin_fabsf(dtw[i]) <= 0.25f) sincos_small_spec(dtw[i], sd[i], cd[i]);
             else sincos_spec(dtw[i], sd[i], cd[i]);
         }
@@ -483,32 +375,33 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 c0[i] = c[i];
                 s0[i] = s[i];
             }
-            // conservative integer pre-test on int16-quantised collision points (see robogym_kernels.hip)
+            // conservative pre-tests (kernel_args.h): one boundary test per chunk on its first positions
+            // widened by the chunk's travel; per sub-step the collision points rounded to binary16 pairs
             int dmin = 0x7FFFFFFF;
-            float bx_lo = x[0], bx_hi = x[0], by_lo = y[0], by_hi = y[0];
-            sfor<0, C>([&](auto UU) {
-                int q[N];
+            float bmax_x = 0.0f, bmax_y = 0.0f;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    bx_lo = fminf(bx_lo, x[i]);
-                    bx_hi = fmaxf(bx_hi, x[i]);
-                    by_lo = fminf(by_lo, y[i]);
-                    by_hi = fmaxf(by_hi, y[i]);
-                    const float fxx = __builtin_fmaf(k.coll_off, c[i], x[i]), fyy = __builtin_fmaf(k.coll_off, s[i], y[i]);
-                    q[i] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pknorm_i16(fxx * 0.25f, fyy * 0.25f));
-                }
+            for (int i = 0; i < N; ++i) {
+                bmax_x = fmaxf(bmax_x, __builtin_fabsf(x[i] - k.xc) + mrg[i]);
+                bmax_y = fmaxf(bmax_y, __builtin_fabsf(y[i] - k.yc) + mrg[i]);
+            }
+            const bool bnd_any = (bmax_x > k.xh) | (bmax_y > k.yh);
+            sfor<0, C>([&](auto UU) {
+                half2v q[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    q[i] = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(k.coll_off, c[i], x[i]), __builtin_fmaf(k.coll_off, s[i], y[i])));
                 for_pairs<N>([&](auto II, auto JJ) {
                     constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
-                    const short2v dq = __builtin_elementwise_sub_sat(__builtin_bit_cast(short2v, q[i]),
-                                                                     __builtin_bit_cast(short2v, q[j]));
-                    int d2;
-                    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2) : "v"(dq));
+                    const half2v dq = q[i] - q[j];
+                    const int d2 = dot2_bits(dq);
                     dmin = d2 < dmin ? d2 : dmin;
                 });
                 advance(x, y, c, s);
             });
-            const bool bnd_any = (bx_lo < k.xmin) | (bx_hi > k.xmax) | (by_lo < k.ymin) | (by_hi > k.ymax);
-            if (penalize && ((dmin <= thr_q) | bnd_any)) {
+            if (penalize && ((dmin <= thr_pre) | bnd_any)) {
+#ifdef RG_TPE_DIAG
+                diag |= 1 << (16 + (it0 ? 3 : 0) + j0 / CH);
+#endif
                 // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
@@ -532,7 +425,9 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         int j = 0;
         bool ok = true;
         for (; ok && j + CH <= n; j += CH) ok = run_chunk(std::integral_constant<int, CH>{}, j);
-        for (; ok && j < n; ++j) ok = run_chunk(std::integral_constant<int, 1>{}, j);
+        sfor<1, CH>([&](auto RR) {  // the remainder as one shorter chunk
+            if (ok && n - j == decltype(RR)::value) ok = run_chunk(RR, j);
+        });
         // period end: heading and distance for the sub-steps this env executed
         const float ne = static_cast<float>(n_exec);
 #pragma unroll
@@ -880,9 +775,34 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
         a.io.done[e] = done ? 1 : 0;
         a.io.violation[e] = static_cast<uint8_t>(viol);
         a.io.remaining[e] = remaining;
+#ifdef RG_TPE_DIAG
+        max_sweeps = diag;  // diagnostic build: replayed-chunk mask << 16 | sweeps of QP 1 << 8 | sweeps of QP 2
+#endif
         if (a.io.qp_sweeps) a.io.qp_sweeps[e] = max_sweeps;
     }
-    if (a.auto_reset && done) reset_env<SCN>(a, e, perm_lds[threadIdx.x]);
+    return done;
+}
+
+// ------------------------------------------------------------------ the step kernel
+template <int SCN, int N>
+// (forcing the register budget of 3 waves per SIMD with amdgpu_waves_per_eu spills ~100 VGPRs at N = 5
+// and measured 1.7x slower; the natural allocation runs 2 waves per SIMD at N = 5, 6 and 3 at N <= 4)
+__global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
+    __shared__ Lds<WAVE> lds;
+    const int e = blockIdx.x * WAVE + threadIdx.x;
+    bool done = false;
+    if (e < a.E) done = step_env<SCN, N>(a, e);
+    // fused auto-reset (scenario.reset(); ~1 env in 70 per step): the whole wave resets each finished
+    // env together, as one 64-lane group of the shared sampler
+    if (a.auto_reset) {
+        unsigned long long todo = __ballot(done);
+        if (todo) __syncthreads();  // the wave's state stores are complete before other lanes rewrite them
+        while (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            reset_group<SCN, WAVE>(a, lds, blockIdx.x * WAVE + i, 0, threadIdx.x, true);
+        }
+    }
 }
 
 template <int SCN>
@@ -926,8 +846,8 @@ hipError_t launch_step_tpe(const KernelArgs &a, hipStream_t stream) {
         case RG_SCN_SIMPLE:
             return tpe::launch_scn<RG_SCN_SIMPLE>(a, stream);
         case RG_SCN_ARCTIC_TRANSPORT: {
-            const int grid = (a.E + tpe::WAVE - 1) / tpe::WAVE;
-            hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4>), dim3(grid), dim3(tpe::WAVE), 0, stream, a);
+            const int grid = (a.E + WAVE - 1) / WAVE;
+            hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4>), dim3(grid), dim3(WAVE), 0, stream, a);
             return hipGetLastError();
         }
         default:
