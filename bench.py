@@ -35,7 +35,7 @@ def measured_traffic():
         import csv
         kb = {}
         for r in csv.DictReader(open(path)):
-            if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and "rg::step_kernel<0, 8" in r["kernel"]:
                 kb[r["counter"]] = float(r["mean_per_launch"])
         if len(kb) == 2:
             return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, "profiles/r1_final_pmc_summary.csv"
@@ -86,6 +86,41 @@ def cpu_baseline(seconds_budget=12.0):
             "c_oracle_f64_1core": c_rate}
 
 
+SATURATED_ENVS = 524288
+
+
+def saturated_leg(dev, overrides):
+    """The same step at a batch that fills the chip (524288 envs, thread-per-env kernel): where the
+    path stands against the HBM roof when launch latency no longer binds.  Reported beside the
+    headline, never as `value`."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    E = SATURATED_ENVS
+    env = VecRobotariumEnv("PredatorCapturePrey", E, overrides=overrides, device=dev, seed=0, auto_reset=True)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    acts = torch.randint(0, 5, (8, E, env.N), generator=gen, device=dev, dtype=torch.int32)
+    ptrs = [acts[i].data_ptr() for i in range(8)]
+    env.reset()
+    for i in range(40):
+        env.step_raw(ptrs[i % 8])
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    K = 100
+    a.record()
+    for i in range(K):
+        env.step_raw(ptrs[i % 8])
+    b.record()
+    torch.cuda.synchronize(dev)
+    ms = a.elapsed_time(b) / K
+    gbs = ALGO_BYTES_PER_ENV_STEP * E / (ms * 1e-3) / 1e9
+    out = {"envs": E, "kernel": "rg::tpe::step_kernel<PCP,N=5> (one lane per env)", "steps": K,
+           "ms_per_step": ms, "agent_steps_per_s": E * env.N / (ms * 1e-3),
+           "hbm_achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+    env.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-saturated", action="store_true", help="skip the 524288-env side measurement")
     ap.add_argument("--scenario", default="PredatorCapturePrey")
     ap.add_argument("--dist-backend", default=None, help="nccl (default, = RCCL) | gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -193,7 +229,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "rg::step_kernel<PCP,GW=8>",
+                         "kernel": "rg::step_kernel<PCP,GW=8> (lane group per env)" if E < 32768
+                                   else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)",
                          "kernel_ms_avg": gpu_ms_total / K,   # HIP events around the timed region / K (back-to-back launches)
                          "kernel_ms_avg_event_pair_per_launch": kernel_ms,
                          "kernel_ms_median_event_pair_per_launch": kernel_ms_median,
@@ -207,6 +244,8 @@ def main():
             out["episodes"] = {"finished": n_ep,
                                "mean_return": float(rs.sum().item() / max(n_ep, 1)),
                                "mean_length": float(ss.sum().item() / max(n_ep, 1))}
+        if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey":
+            out["saturated"] = saturated_leg(dev, overrides)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -28,3 +28,12 @@ for i in range(150):
         tot["replay_env"] += float(pop(mask).mean()); tot["replay_wave"] += float(pop(wave_mask).mean())
         n += 1
 print({k: round(v / n, 3) for k, v in tot.items()})
+d = env.qp_sweeps
+for name, sw in (("QP1", (d >> 8) & 255), ("QP2", d & 255)):
+    h = torch.bincount(sw.flatten(), minlength=20).float()
+    h = h / h.sum()
+    print(name, "sweep histogram (fraction of envs):", [round(float(x), 5) for x in h[:20]])
+    for g in (8, 64):
+        m = sw.view(-1, g).max(dim=1).values
+        hh = torch.bincount(m, minlength=20).float()
+        print(f"   max over {g} envs:", [round(float(x), 4) for x in (hh / hh.sum())[:20]])
