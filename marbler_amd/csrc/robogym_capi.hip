@@ -61,6 +61,8 @@ static int check_params(const rg_scenario_params *p) {
         const int od = p->capability_aware ? 6 : 4;
         const int nb = p->num_neighbors >= p->n_agents - 1 ? p->n_agents - 1 : p->num_neighbors;
         if (p->obs_dim < od * (nb + 1)) return fail(-10, "obs_dim too small for PredatorCapturePrey");
+        // the 4-float observation blocks are written with 16-byte stores
+        if (od == 4 && (p->obs_dim & 3)) return fail(-10, "obs_dim must be a multiple of 4 for PredatorCapturePrey without capability_aware");
     } else if (p->scenario == RG_SCN_WAREHOUSE) {
         const int nb = p->num_neighbors >= p->n_agents - 1 ? p->n_agents - 1 : p->num_neighbors;
         if (p->obs_dim < 3 * (nb + 1)) return fail(-10, "obs_dim too small for Warehouse");

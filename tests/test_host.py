@@ -41,6 +41,28 @@ def test_create_rejects_bad_parameters_without_touching_a_gpu():
     assert not lib.rg_create(ctypes.byref(p), 4, 0, 0, None)
     assert b"n_agents" in lib.rg_last_error()
     assert lib.rg_destroy(None) != 0 and lib.rg_step(None, None, None, 0, 0) != 0
+    # every check_params branch: each bad field is named in the error text
+    base = lambda scn="PredatorCapturePrey": make_params(scn, load_config(scn))  # noqa: E731
+    for scn, field, value, word in (("PredatorCapturePrey", "obs_dim", 18, b"multiple of 4"),
+                                    ("PredatorCapturePrey", "obs_dim", 8, b"obs_dim too small"),
+                                    ("PredatorCapturePrey", "num_prey", 0, b"num_prey"),
+                                    ("PredatorCapturePrey", "update_frequency", 0, b"update_frequency"),
+                                    ("PredatorCapturePrey", "qp_max_sweeps", 0, b"qp_max_sweeps"),
+                                    ("PredatorCapturePrey", "collision_variant", 7, b"collision_variant"),
+                                    ("PredatorCapturePrey", "scenario", 9, b"scenario"),
+                                    ("Warehouse", "obs_dim", 5, b"obs_dim too small"),
+                                    ("MaterialTransport", "obs_dim", 5, b"obs_dim too small"),
+                                    ("ArcticTransport", "n_agents", 5, b"4 agents"),
+                                    ("Simple", "num_prey", 2, b"one goal")):
+        q = base(scn)
+        setattr(q, field, value)
+        assert not lib.rg_create(ctypes.byref(q), 4, 0, 0, None), (scn, field)
+        assert word in lib.rg_last_error(), (scn, field, lib.rg_last_error())
+    q = base()
+    q.agent_grid.nx = 1
+    q.agent_grid.ny = 2
+    assert not lib.rg_create(ctypes.byref(q), 4, 0, 0, None) and b"reset grid" in lib.rg_last_error()
+    assert not lib.rg_create(ctypes.byref(base()), 0, 0, 0, None) and b"num_envs" in lib.rg_last_error()
 
 
 def test_no_cpu_fallback():
