@@ -48,6 +48,18 @@ __device__ __forceinline__ float xor_lane(float v) {
     return __builtin_bit_cast(float, xor_lane_i<K>(__builtin_bit_cast(int, v)));
 }
 
+// groups of 8 lanes: lane M of the lower quad's neighbour quad, i.e. lanes 0..3 receive lane 4+M and
+// lanes 4..7 receive lane M (quad broadcast, then half-row mirror)
+template <int M>
+__device__ __forceinline__ int cross_lane_i(int v) {
+    static_assert(M >= 0 && M <= 3, "quad lane");
+    return dpp_i<0x141>(dpp_i<(M | (M << 2) | (M << 4) | (M << 6))>(v));
+}
+template <int M>
+__device__ __forceinline__ float cross_lane(float v) {
+    return __builtin_bit_cast(float, cross_lane_i<M>(__builtin_bit_cast(int, v)));
+}
+
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 // bits of d.x*d.x + d.y*d.y in binary32 (VOP3P v_dot2_f32_f16 with a literal-zero addend; the
 // compiler's own selection is v_dot2c, which costs an extra v_mov to clear the accumulator)
@@ -144,6 +156,40 @@ __device__ __forceinline__ void fisher_yates2(Lds<GW> &lds, int g, int ag, bool 
                                               int count_a, int first_a, const rg_grid &grid_b, int count_b,
                                               int first_b) {
     const int Ca = grid_a.nx * grid_a.ny, Cb = count_b > 0 ? grid_b.nx * grid_b.ny : 0;
+    constexpr int RMAX = 8;
+    if (count_a <= RMAX && count_b <= RMAX) {
+        // short draws (the reference's scenarios: 4..8 agents, 6 prey): the same partial Fisher-Yates without
+        // the permutation array.  Position p holds p unless an earlier step k swapped something into it
+        // (j_k == p, value t_k = what position k held then); the latest such step wins.  All in registers:
+        // no dependent LDS round trips on the chain.
+        __syncthreads();  // the Philox draws are in LDS
+        if (do_reset && ag < 2) {
+            const int which = ag;
+            const int C = which ? Cb : Ca, count = which ? count_b : count_a, first = which ? first_b : first_a;
+            uint32_t r[RMAX];
+#pragma unroll
+            for (int i = 0; i < RMAX; ++i) r[i] = lds.draws[g][first + (i < count ? i : 0)];
+            int jpos[RMAX], tval[RMAX];
+            const int cmax = count_a > count_b ? count_a : count_b;
+#pragma unroll
+            for (int i = 0; i < RMAX; ++i) {
+                if (i >= cmax) break;  // wave-uniform
+                const int j = i + static_cast<int>((static_cast<uint64_t>(r[i]) * static_cast<uint32_t>(C - i)) >> 32);
+                int t = i, sv = j;
+#pragma unroll
+                for (int q = 0; q < i; ++q) {
+                    t = (jpos[q] == i) ? tval[q] : t;
+                    sv = (jpos[q] == j) ? tval[q] : sv;
+                }
+                sv = (j == i) ? t : sv;
+                jpos[i] = j;
+                tval[i] = t;
+                if (i < count) lds.sel[g][which][i] = static_cast<uint8_t>(sv);
+            }
+        }
+        __syncthreads();
+        return;
+    }
     if (do_reset) {
         for (int i = ag; i < Ca; i += GW) lds.perm[g][0][i] = static_cast<uint8_t>(i);
         for (int i = ag; i < Cb; i += GW) lds.perm[g][1][i] = static_cast<uint8_t>(i);

@@ -242,7 +242,9 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
 #endif
 
 // ------------------------------------------------------------------ the step kernel
-template <int SCN, int GW, bool OBS_ONLY>
+// NT: the agent count when it is a compile-time constant (instantiated for GW = 8: 5..8), 0 = read
+// it from the parameter block.
+template <int SCN, int GW, bool OBS_ONLY, int NT = 0>
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     constexpr int EPW = WAVE / GW;  // envs per wave
 #ifdef RG_STAMPS
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ Lds<GW> lds;
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
-    const int N = p.n_agents;
+    const int N = NT > 0 ? NT : p.n_agents;
     const int lane = threadIdx.x;
     const int ag = lane & (GW - 1);
     const int g = lane / GW;
@@ -459,12 +461,23 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                 int dmin = 0x7FFFFFFF;
                 static_for<0, C>([&](auto UU) {
                     constexpr int u = decltype(UU)::value;
-                    static_for<1, GW>([&](auto KK) {
-                        constexpr int K = decltype(KK)::value;
-                        const half2v dq = __builtin_bit_cast(half2v, q[u]) - __builtin_bit_cast(half2v, xor_lane_i<K>(q[u]));
+                    auto test = [&](int partner_q) {
+                        const half2v dq = __builtin_bit_cast(half2v, q[u]) - __builtin_bit_cast(half2v, partner_q);
                         const int d2 = dot2_bits(dq);
                         dmin = d2 < dmin ? d2 : dmin;
-                    });
+                    };
+                    if constexpr (GW == 8 && NT >= 5 && NT <= 7) {
+                        // the pre-test may visit the pairs in any order: the three quad rounds cover the
+                        // pairs inside each quad, then each agent of the upper quad (4 .. N-1) is broadcast
+                        // over its quad and mirrored onto the lower one: 3 + (N-4) rounds instead of 7
+                        static_for<1, 4>([&](auto KK) { test(xor_lane_i<decltype(KK)::value>(q[u])); });
+                        static_for<0, NT - 4>([&](auto MM) {
+                            constexpr int M = decltype(MM)::value;
+                            test(cross_lane_i<M>(q[u]));
+                        });
+                    } else {
+                        static_for<1, GW>([&](auto KK) { test(xor_lane_i<decltype(KK)::value>(q[u])); });
+                    }
                 });
                 if (penalize && __any((dmin <= thr_pre) | bnd_any)) {
                     // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
@@ -473,11 +486,24 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
                         const bool bnd = lane_ok & !dead & ((rx < k.xmin) | (rx > k.xmax) | (ry < k.ymin) | (ry > k.ymax));
                         const float fx = __builtin_fmaf(k.coll_off, rc, rx), fy = __builtin_fmaf(k.coll_off, rs, ry);
                         bool col = false;
-                        static_for<1, GW>([&](auto KK) {
-                            constexpr int K = decltype(KK)::value;
-                            const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
-                            col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
-                        });
+                        if constexpr (GW == 8 && NT >= 5 && NT <= 7) {  // same pair cover as the pre-test: 3 + (N-4) rounds
+                            static_for<1, 4>([&](auto KK) {
+                                constexpr int K = decltype(KK)::value;
+                                const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
+                                col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
+                            });
+                            static_for<0, NT - 4>([&](auto MM) {  // lower lanes meet agent 4+M, upper lanes agent M
+                                constexpr int M = decltype(MM)::value;
+                                const float dx = fx - cross_lane<M>(fx), dy = fy - cross_lane<M>(fy);
+                                col = col | (dx * dx + dy * dy <= k.coll_lim2);
+                            });
+                        } else {
+                            static_for<1, GW>([&](auto KK) {
+                                constexpr int K = decltype(KK)::value;
+                                const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
+                                col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
+                            });
+                        }
                         col = col & lane_ok & !dead;
                         const int code = (group_any<GW>(col, gbase) ? 1 : 0) | (group_any<GW>(bnd, gbase) ? 2 : 0);
                         rx = __builtin_fmaf(rc, dtv, rx);  // the violating sub-step is still integrated
@@ -981,8 +1007,12 @@ static hipError_t launch_step_scn(const KernelArgs &a, hipStream_t stream) {
     const int gw = group_width(a.p.n_agents);
     const int grid = (a.E + WAVE / gw - 1) / (WAVE / gw);
     if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else if (gw == 8) hipLaunchKernelGGL((step_kernel<SCN, 8, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else hipLaunchKernelGGL((step_kernel<SCN, 16, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if (gw == 16) hipLaunchKernelGGL((step_kernel<SCN, 16, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if constexpr (OBS_ONLY) hipLaunchKernelGGL((step_kernel<SCN, 8, true>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if (a.p.n_agents == 5) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 5>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if (a.p.n_agents == 6) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 6>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if (a.p.n_agents == 7) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 7>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else hipLaunchKernelGGL((step_kernel<SCN, 8, false, 8>), dim3(grid), dim3(WAVE), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -21,3 +21,18 @@ q = torch.stack(qs).mean(0)
 print("mean over launches of the k-th slowest wave's end tick:")
 for name, v in zip(["top1", "top2", "top4", "top8", "top16", "top32", "top64", "top128", "median", "fastest", "mean"], q):
     print(f"  {name:8s} {float(v):8.0f}")
+# phase breakdown of the slowest wave of each launch, and of the 8th slowest
+names = ["loaded", "ctrl1", "period1", "periods", "epilogue", "stored", "reset"]
+env.reset()
+top, top8, cnt = torch.zeros(8, dtype=torch.float64), torch.zeros(8, dtype=torch.float64), 0
+for i in range(400):
+    env.step(acts[i % 64])
+    if i >= 100:
+        s = env.qp_sweeps.view(-1, 8).double()
+        order = s[:, 6].argsort(descending=True)
+        top += s[order[0]].cpu()
+        top8 += s[order[7]].cpu()
+        cnt += 1
+for label, t in (("slowest wave", top / cnt), ("8th slowest", top8 / cnt)):
+    prev = 0.0
+    print(label + ": " + "  ".join(f"{n} +{float(t[k]) - (float(t[k-1]) if k else 0):.0f}" for k, n in enumerate(names)) + f"  (sweeps of its first env {float(t[7]):.1f})")
