@@ -87,6 +87,33 @@ def cpu_baseline(seconds_budget=12.0):
 
 
 SATURATED_ENVS = 524288
+ROLLOUT_STEPS_PER_LAUNCH = 64
+
+
+def rollout_leg(env, dev, n_act, seed, launches=16):
+    """The same envs driven through rg_rollout: 64 env steps per launch for a pre-generated action
+    sequence (what a random-policy rollout is), every step's outputs written to [64, ...] buffers.
+    Envs advance independently inside the launch, so a launch costs 64 mean steps instead of 64
+    slowest-wave steps.  Reported beside the headline (which stays one rg_step launch per step, the
+    call a policy-in-the-loop trainer makes)."""
+    import torch
+    K = ROLLOUT_STEPS_PER_LAUNCH
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    acts = torch.randint(0, n_act, (K, env.E, env.N), generator=gen, device=dev, dtype=torch.int32)
+    buf = env.rollout(acts)
+    env.rollout(acts, out=buf)
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(launches):
+        env.rollout(acts, out=buf)
+    b.record()
+    torch.cuda.synchronize(dev)
+    ms = a.elapsed_time(b) / (launches * K)
+    gbs = ALGO_BYTES_PER_ENV_STEP * env.E / (ms * 1e-3) / 1e9
+    return {"api": "rg_rollout", "steps_per_launch": K, "launches": launches, "ms_per_step": ms,
+            "agent_steps_per_s": env.E * env.N / (ms * 1e-3), "hbm_achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
 
 
 def saturated_leg(dev, overrides):
@@ -224,7 +251,7 @@ def main():
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scenario}-v0, {E} envs x {N} agents per GPU, random policy, "
-                                   f"auto-reset, update_frequency {env.params.update_frequency}",
+                                   f"auto-reset, update_frequency {env.params.update_frequency}, one rg_step launch per env step",
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -245,6 +272,7 @@ def main():
                                "mean_return": float(rs.sum().item() / max(n_ep, 1)),
                                "mean_length": float(ss.sum().item() / max(n_ep, 1))}
         if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey":
+            out["rollout"] = rollout_leg(env, dev, n_act, 777)
             out["saturated"] = saturated_leg(dev, overrides)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

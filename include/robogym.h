@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 1
+#define RG_ABI_VERSION 2
 #define RG_MAX_AGENTS 16
 #define RG_MAX_PREY 64
 
@@ -168,6 +168,15 @@ int rg_reset(rg_handle *h, const uint8_t *mask, uint64_t seed);
  * actions: [E][N] int32.  If auto_reset != 0, envs that finish are reset in the same launch
  * (their returned obs/reward/done are those of the terminal step). */
 int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t auto_reset, uint64_t seed);
+
+/* num_steps consecutive rg_step()s in ONE launch, for action sequences that are known up front
+ * (random-policy rollouts -- misc.py:134-221 `run_env` with a random policy --, replayed logs,
+ * open-loop plans).  actions: [K][E][N]; every array of io has a leading dimension K and receives
+ * what the k-th rg_step would have returned; results are bit-identical to K calls of rg_step.
+ * Envs advance independently inside the launch (no device-wide synchronisation between steps), so
+ * the launch takes K mean steps, not K worst-case steps. */
+int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg_step_io *io, int32_t auto_reset,
+               uint64_t seed);
 
 /* The observation the scenario would build from the current state without stepping (the
  * reference returns zeros from reset(), PredatorCapturePrey.py:136; EPyMARL's gymma layer is

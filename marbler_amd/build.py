@@ -14,9 +14,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librobogym_hip.so")
-SOURCES = ["robogym_kernels.hip", "robogym_tpe.hip", "robogym_capi.hip"]
-HEADERS = [os.path.join(CSRC, "sim_math.h"), os.path.join(CSRC, "kernel_args.h"), os.path.join(CSRC, "device_common.h"),
-           os.path.join(HERE, "..", "include", "robogym.h")]
+SOURCES = ["robogym_kernels.hip", "robogym_rollout_group.hip", "robogym_tpe.hip", "robogym_rollout_tpe.hip",
+           "robogym_capi.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("sim_math.h", "kernel_args.h", "device_common.h", "step_group.h", "step_tpe.h")] + \
+          [os.path.join(HERE, "..", "include", "robogym.h")]
 ARCH = "gfx950"
 
 
@@ -40,12 +41,27 @@ def build(force=False, verbose=False, defines=(), out=None):
     if out is None and not force and not needs_build():
         return LIB
     out = out or LIB
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-fPIC", "-shared", "-std=c++17",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + [f"-D{d}" for d in defines] + ["-o", out] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    # one object per translation unit, compiled side by side (the kernel instantiations dominate:
+    # ~2 min each for the lane-group files, ~1 min for the thread-per-env ones), then one link
+    objdir = os.path.join(HERE, "build", os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
+             "-Wno-unused-function"] + [f"-D{d}" for d in defines]
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc_path()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return out
 
 

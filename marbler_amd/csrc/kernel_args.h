@@ -70,6 +70,7 @@ struct KernelArgs {
     const int32_t *actions;
     const uint8_t *reset_mask;
     int32_t E;
+    int32_t num_steps;  // env steps per launch (rg_step: 1); io and actions carry a leading dimension of this size
     int32_t auto_reset;
     int64_t env_offset;
     uint64_t seed;
@@ -77,8 +78,30 @@ struct KernelArgs {
 
 hipError_t launch_step(const KernelArgs &a, bool obs_only, hipStream_t stream);
 hipError_t launch_reset(const KernelArgs &a, hipStream_t stream);
+
+// the k-th step's slice of the action and output arrays
+struct StepView {
+    const int32_t *actions;
+    rg_step_io io;
+};
+__host__ __device__ inline StepView step_view(const KernelArgs &a, int k, int n_agents, int obs_dim) {
+    StepView v;
+    const size_t e = static_cast<size_t>(a.E) * k, en = e * n_agents;
+    v.actions = a.actions ? a.actions + en : nullptr;
+    v.io.obs = a.io.obs ? a.io.obs + en * obs_dim : nullptr;
+    v.io.reward = a.io.reward ? a.io.reward + en : nullptr;
+    v.io.done = a.io.done ? a.io.done + e : nullptr;
+    v.io.dist_travelled = a.io.dist_travelled ? a.io.dist_travelled + en : nullptr;
+    v.io.violation = a.io.violation ? a.io.violation + e : nullptr;
+    v.io.remaining = a.io.remaining ? a.io.remaining + e : nullptr;
+    v.io.qp_sweeps = a.io.qp_sweeps ? a.io.qp_sweeps + e : nullptr;
+    return v;
+}
 // thread-per-env step kernel (robogym_tpe.hip): same results, chosen by the host for large batches
 bool tpe_supported(const rg_scenario_params &p);
 hipError_t launch_step_tpe(const KernelArgs &a, hipStream_t stream);
+// rg_rollout: num_steps env steps per launch (robogym_rollout_group.hip, robogym_rollout_tpe.hip)
+hipError_t launch_rollout(const KernelArgs &a, hipStream_t stream);
+hipError_t launch_rollout_tpe(const KernelArgs &a, hipStream_t stream);
 
 }  // namespace rg

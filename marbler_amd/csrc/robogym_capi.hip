@@ -173,6 +173,7 @@ static int fill_args(rg_handle *h, rg::KernelArgs &a) {
     a.k = h->consts;
     a.st = h->state;
     a.E = h->num_envs;
+    a.num_steps = 1;
     a.env_offset = h->env_offset;
     return 0;
 }
@@ -202,6 +203,39 @@ int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t 
     a.auto_reset = auto_reset;
     a.seed = seed;
     return launched(h->use_tpe ? rg::launch_step_tpe(a, h->stream) : rg::launch_step(a, false, h->stream));
+}
+
+int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg_step_io *io, int32_t auto_reset,
+               uint64_t seed) {
+    rg::KernelArgs a;
+    if (int rc = fill_args(h, a)) return rc;
+    if (!actions || !io) return fail(-23, "actions or io is NULL");
+    if (num_steps < 1) return fail(-27, "num_steps < 1");
+    if (!io->obs || !io->reward || !io->done || !io->dist_travelled || !io->violation || !io->remaining)
+        return fail(-24, "every rg_step_io array except qp_sweeps is required");
+    if (reinterpret_cast<uintptr_t>(io->obs) & 15u) return fail(-26, "obs must be 16-byte aligned");
+    // every step's [E][N][D] slice must keep the 16-byte alignment of the block stores
+    if ((static_cast<size_t>(h->num_envs) * h->params.n_agents * h->params.obs_dim) & 3u)
+        return fail(-26, "E*N*D must be a multiple of 4 for rg_rollout");
+    a.actions = actions;
+    a.io = *io;
+    a.num_steps = num_steps;
+    a.auto_reset = auto_reset;
+    a.seed = seed;
+    if (!h->use_tpe) return launched(rg::launch_rollout(a, h->stream));
+    // thread-per-env: the multi-step kernel holds more values live (313 VGPRs at N = 5: one wave per
+    // SIMD); it pays while the batch is at most one wave per SIMD (the latency regime), beyond that
+    // num_steps single-step launches are faster (measured at 524288 envs: 166 vs 197 us per step)
+    if (h->num_envs <= 65536) return launched(rg::launch_rollout_tpe(a, h->stream));
+    a.num_steps = 1;
+    for (int32_t k = 0; k < num_steps; ++k) {
+        const rg::StepView v = rg::step_view(a, k, h->params.n_agents, h->params.obs_dim);
+        rg::KernelArgs ak = a;
+        ak.actions = v.actions;
+        ak.io = v.io;
+        if (int rc = launched(rg::launch_step_tpe(ak, h->stream))) return rc;
+    }
+    return 0;
 }
 
 int rg_get_obs(rg_handle *h, float *obs) {

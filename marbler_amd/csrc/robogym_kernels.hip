@@ -1,1020 +1,8 @@
-// robogym_kernels.hip -- the fused env-step kernel for gfx950 (MI355X, CDNA4).
-//
-// One launch = one env step for E envs: goal generation, U sim sub-iterations (controller with
-// the barrier-certificate QP every 15th, collision/boundary validation, Euler integration),
-// then the scenario's tracking / observation / reward / termination, and the reset of envs that
-// finished -- all with the env's state in registers.  HBM traffic is the algorithmic I/O only
-// (measured with rocprofv3 FETCH_SIZE / WRITE_SIZE in profiles/).
-//
-// Mapping: a lane GROUP of GW lanes (GW = 4, 8 or 16 >= N) owns one env, one lane per agent; a
-// 64-lane wavefront carries 64/GW envs; one wavefront per workgroup (no cross-wave sync
-// anywhere).  The O(N^2) pair work (collision scan, QP constraint sweeps) runs as GW-1
-// "rounds": in round k lane a is paired with lane a^k, a 1-factorisation of the complete graph
-// on the group -- disjoint pairs, so a Gauss-Seidel sweep over the QP constraints in this
-// order is pair-parallel yet identical to the sequential sweep of the CPU oracle.  Partner
-// data moves by DPP (row-local lane permutes on the VALU), never through memory; per-env
-// reductions are DPP butterflies or one wave ballot; the per-env prey block and the agents'
-// own-observation rows are staged in LDS.
-//
-// No MFMA: there is no dense contraction on this path.  At the benchmark size (4096 envs =
-// 512 wavefronts on 1024 SIMDs) the kernel is a latency-bound dependent chain per wavefront, so
-// the design goal is the shortest per-lane instruction chain with independent work interleaved
-// (sub-steps are processed in chunks of 4 for ILP), not bytes.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include <type_traits>
-
-#include "device_common.h"
+// robogym_kernels.hip -- instantiates the lane-group kernels (step_group.h) for one env step per launch
+// (rg_step, rg_get_obs) and the explicit reset (rg_reset).
+#include "step_group.h"
 
 namespace rg {
-
-#ifndef RG_CHUNK
-#define RG_CHUNK 5
-#endif
-// sub-steps validated together (ILP across independent test chains).  The controller periods of the
-// reference's configurations are 15 and 14 sub-steps: three chunks of 5, or two and a remainder chunk of 4.
-constexpr int CHUNK = RG_CHUNK;
-
-// ------------------------------------------------------------------ controller (a3..a8)
-// utilities/controller.py:20-24 over the restated rps closures,
-// followed by Robotarium.set_velocities' clipping.  Called in wave-uniform control flow.
-template <int GW>
-__device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, int N, int ag, bool lane_ok,
-                                          bool upd, float x, float y, float c, float s, float gx, float gy, float &v,
-                                          float &w) {
-    // a4 uni_to_si_states, a5 si_position_controller (gain 1, |dxi| <= 0.15)
-    const float xix = x + k.pd * c, xiy = y + k.pd * s;
-    float ux = gx - xix, uy = gy - xiy;
-    {
-        const float nrm = norm2_spec(ux, uy);
-        const float sc = k.pvl / nrm;
-        const bool clip = nrm > k.pvl;
-        ux = clip ? ux * sc : ux;
-        uy = clip ? uy * sc : uy;
-    }
-    // a6 barrier certificate: rows e_ij.(u_j - u_i) <= beta_ij, one per round; the exact projection
-    // by Hildreth sweeps with Aitken restarts (algorithm and derivation: oracle/oracle_core.h
-    // barrier_qp).  Per round: f = e/n2, bp = beta/n2, emax = max(|ex|, |ey|); absent pairs have
-    // f = bp = emax = 0 and mu = 0, which makes every update of theirs an exact no-op.
-    const float bgain = p.barrier_gain, ugain = p.unsafe_barrier_gain, qp_rtol = p.qp_rtol;
-    const int qp_cap = p.qp_max_sweeps;
-    const bool has_unsafe = p.barrier_has_unsafe_gain != 0;
-    float ex[GW - 1], ey[GW - 1], fx[GW - 1], fy[GW - 1], bp[GW - 1], emax[GW - 1];
-    float mu[GW - 1], muA[GW - 1], muB[GW - 1];
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        const float pxi = xor_lane<K>(xix), pyi = xor_lane<K>(xiy);
-        const float dx = xix - pxi, dy = xiy - pyi;
-        const float ee = dx * dx + dy * dy;
-        const float h = ee - k.r2;
-        const float gain = ((h >= 0.0f) | !has_unsafe) ? bgain : ugain;
-        const float b = gain * ((h * h) * h);
-        const float n2 = 2.0f * ee;
-        const bool ok = lane_ok & ((ag ^ K) < N) & (n2 > 0.0f);
-        const float rn2 = ok ? 1.0f / n2 : 0.0f;
-        ex[K - 1] = dx;
-        ey[K - 1] = dy;
-        fx[K - 1] = dx * rn2;
-        fy[K - 1] = dy * rn2;
-        bp[K - 1] = (0.5f * b) * rn2;
-        emax[K - 1] = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
-        mu[K - 1] = muA[K - 1] = muB[K - 1] = 0.0f;
-    });
-    {   // "Threshold control inputs before QP": decided on squares; never taken after the 0.15 clip
-        const float n2u = ux * ux + uy * uy;
-        const bool clip = n2u > k.bml * k.bml;
-        if (__any(clip)) {
-            const float sc = k.bml / __builtin_sqrtf(n2u);
-            ux = clip ? ux * sc : ux;
-            uy = clip ? uy * sc : uy;
-        }
-    }
-    const float uhx = ux, uhy = uy;
-    // A group drops out when converged (its lanes are exec-masked for the whole sweep body: groups
-    // are uniform, so an active lane never reads a masked partner); the wave loops while any group
-    // is active.
-    bool active = upd;
-    int sweeps = 0, my_sweeps = 0;
-    // one sweep over the GW-1 rounds + the convergence test; PHASE = sweep number mod 4 selects the
-    // Aitken bookkeeping (record mu after sweeps 1 and 2 of each block of four, restart after the 3rd)
-    auto sweep = [&](auto PH) {
-        constexpr int PHASE = decltype(PH)::value;
-        ++sweeps;
-        if (active) {
-            float chg = 0.0f;
-            static_for<1, GW>([&](auto KK) {
-                constexpr int K = decltype(KK)::value;
-                const float pux = xor_lane<K>(ux), puy = xor_lane<K>(uy);
-                const float c0 = mu[K - 1] - bp[K - 1];
-                const float t = __builtin_fmaf(fy[K - 1], puy - uy, c0);
-                float mn = __builtin_fmaf(fx[K - 1], pux - ux, t);
-                mn = (mn > 0.0f) ? mn : 0.0f;
-                const float delta = mn - mu[K - 1];
-                mu[K - 1] = mn;
-                ux = __builtin_fmaf(delta, ex[K - 1], ux);
-                uy = __builtin_fmaf(delta, ey[K - 1], uy);
-                chg = fmaxf(chg, __builtin_fabsf(delta) * emax[K - 1]);
-                if constexpr (PHASE == 1) muA[K - 1] = mn;
-                if constexpr (PHASE == 2) muB[K - 1] = mn;
-            });
-            my_sweeps = sweeps;
-            const float um = lane_ok ? fmaxf(__builtin_fabsf(ux), __builtin_fabsf(uy)) : 0.0f;
-            const float gchg = group_max_nonneg<GW>(chg);
-            const float gum = fmaxf(k.bml, group_max_nonneg<GW>(um));
-            active = (gchg > qp_rtol * gum) & (sweeps < qp_cap);
-            if constexpr (PHASE == 3) {
-                if (active) {  // Aitken restart of the multipliers, u rebuilt from them
-                    float sx = uhx, sy = uhy;
-                    static_for<1, GW>([&](auto KK) {
-                        constexpr int K = decltype(KK)::value;
-                        const float d1 = muB[K - 1] - muA[K - 1], d2 = mu[K - 1] - muB[K - 1];
-                        const bool geo = (d1 != 0.0f) & (d2 != 0.0f) & ((d1 > 0.0f) == (d2 > 0.0f)) &
-                                         (__builtin_fabsf(d2) < 0.97f * __builtin_fabsf(d1)) & (emax[K - 1] > 0.0f);
-                        float m = mu[K - 1] - (d2 * d2) / (d2 - d1);
-                        m = (m > 0.0f) ? m : 0.0f;
-                        mu[K - 1] = geo ? m : mu[K - 1];
-                        sx = __builtin_fmaf(mu[K - 1], ex[K - 1], sx);
-                        sy = __builtin_fmaf(mu[K - 1], ey[K - 1], sy);
-                    });
-                    ux = sx;
-                    uy = sy;
-                }
-            }
-        }
-    };
-    while (__any(active)) {
-        sweep(std::integral_constant<int, 1>{});
-        if (!__any(active)) break;
-        sweep(std::integral_constant<int, 2>{});
-        if (!__any(active)) break;
-        sweep(std::integral_constant<int, 3>{});
-        if (!__any(active)) break;
-        sweep(std::integral_constant<int, 0>{});
-    }
-    // a7 si_to_uni_dyn, a8 set_velocities
-    float vv = c * ux + s * uy;
-    float ww = k.inv_pd * (-s * ux + c * uy);
-    ww = ww > k.wlim ? k.wlim : ww;
-    ww = ww < -k.wlim ? -k.wlim : ww;
-    vv = vv > k.vmax ? k.vmax : vv;
-    vv = vv < -k.vmax ? -k.vmax : vv;
-    ww = ww > k.wmax ? k.wmax : ww;
-    ww = ww < -k.wmax ? -k.wmax : ww;
-    v = upd ? vv : v;
-    w = upd ? ww : w;
-    return my_sweeps;
-}
-
-// ------------------------------------------------------------------ neighbour observations
-// K nearest neighbours' own-observation rows (staged in LDS) into obs slots 1..K: ascending
-// squared distance, ties -> lower index (the canonical order for misc.py:20-25); K >= N-1: all
-// others in index order.
-template <int GW, int OD>
-__device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb, int ag, int gbase, bool lane_ok,
-                                                    float x, float y, float *obs_row) {
-    // 64-bit sort keys: (bits of the squared distance, partner index) -- non-negative floats order
-    // like their bit patterns, so one unsigned 64-bit compare is the (distance, index) lexicographic
-    // test.  Absent partners get keys above every real one.
-    unsigned long long key[GW - 1];
-    bool ok[GW - 1];
-    int rank[GW - 1];
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        const float2 pxy = *reinterpret_cast<const float2 *>(&lds.own[gbase + (ag ^ K)][0]);  // partner's (x, y)
-        const float dx = pxy.x - x, dy = pxy.y - y;
-        const float d2 = dx * dx + dy * dy;
-        ok[K - 1] = lane_ok & ((ag ^ K) < N);
-        const unsigned int hi = ok[K - 1] ? __builtin_bit_cast(unsigned int, d2) : 0xFFFFFFFFu;
-        key[K - 1] = (static_cast<unsigned long long>(hi) << 32) | static_cast<unsigned int>(ag ^ K);
-        rank[K - 1] = GW - 1 - K;  // pairs in which this round is the first element; each lost comparison adds one below
-    });
-    const bool all_others = Knb >= N - 1;
-    // rank of partner K = number of partners ahead of it: one comparison per unordered pair (Q < K)
-    static_for<2, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        static_for<1, K>([&](auto QQ) {
-            constexpr int Q = decltype(QQ)::value;
-            const int q_first = key[Q - 1] < key[K - 1] ? 1 : 0;
-            rank[K - 1] += q_first;
-            rank[Q - 1] -= q_first;
-        });
-    });
-    // the rows first (independent LDS reads in flight together), then the predicated stores
-    float row[GW - 1][OD];
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        const float *src = &lds.own[gbase + (ag ^ K)][0];
-        if constexpr (OD == 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(src);
-            row[K - 1][0] = v.x;
-            row[K - 1][1] = v.y;
-            row[K - 1][2] = v.z;
-            row[K - 1][3] = v.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < OD; ++c) row[K - 1][c] = src[c];
-        }
-    });
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        const int j = ag ^ K;
-        const int slot = all_others ? (j < ag ? j : j - 1) : rank[K - 1];
-        if (ok[K - 1] & (all_others | (slot < Knb))) {
-            float *o = obs_row + (slot + 1) * OD;
-            if constexpr (OD == 4) {
-                *reinterpret_cast<float4 *>(o) = make_float4(row[K - 1][0], row[K - 1][1], row[K - 1][2], row[K - 1][3]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < OD; ++c) o[c] = row[K - 1][c];
-            }
-        }
-    });
-}
-
-// Diagnostic build only (-DRG_STAMPS, tools/stamp_probe.py): wave-cycle stamps of the step's
-// phases, written over io.qp_sweeps of the wave's first 8 envs.  No stamp executes in the
-// shipped library.
-#ifdef RG_STAMPS
-#define RG_STAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
-#else
-#define RG_STAMP(i)
-#endif
-
-// ------------------------------------------------------------------ the step kernel
-// NT: the agent count when it is a compile-time constant (instantiated for GW = 8: 5..8), 0 = read
-// it from the parameter block.
-template <int SCN, int GW, bool OBS_ONLY, int NT = 0>
-__global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
-    constexpr int EPW = WAVE / GW;  // envs per wave
-#ifdef RG_STAMPS
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    __shared__ Lds<GW> lds;
-    const rg_scenario_params &p = a.p;
-    const Consts &k = a.k;
-    const int N = NT > 0 ? NT : p.n_agents;
-    const int lane = threadIdx.x;
-    const int ag = lane & (GW - 1);
-    const int g = lane / GW;
-    const int gbase = lane & ~(GW - 1);
-    const int e = blockIdx.x * EPW + g;
-    const bool env_ok = e < a.E;
-    const bool lane_ok = env_ok && ag < N;
-    const size_t eN = static_cast<size_t>(e) * N;
-
-    // ---- loads, all issued up front (coalesced: a wave covers EPW consecutive envs = one
-    // contiguous span per array); what the epilogue needs is fetched now so its latency is hidden
-    float x = 0.0f, y = 0.0f, th = 0.0f, carry = 0.0f;
-    int act = 4;
-    int steps = 0;
-    float agent_step = 0.0f, sr = 0.0f, cr = 0.0f;
-    float st_ret = 0.0f, st_sum = 0.0f;
-    int st_cnt = 0, st_steps = 0;
-    const bool stats = (!OBS_ONLY) && a.st.ep_return != nullptr;
-    if (lane_ok) {
-        const float *X = a.st.poses + eN * 3;
-        x = X[ag];
-        y = X[N + ag];
-        th = X[2 * N + ag];
-        agent_step = p.agent_step[ag];
-        if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-            sr = p.sensing_radius[ag];
-            cr = p.capture_radius[ag];
-        }
-        if constexpr (!OBS_ONLY) {
-            carry = a.st.carry_dist[eN + ag];
-            act = a.actions[eN + ag];
-        }
-    }
-    if (env_ok) {
-        steps = a.st.episode_steps[e] + (OBS_ONLY ? 0 : 1);
-        if (stats && ag == 0) {
-            st_ret = a.st.ep_return[e];
-            st_sum = a.st.done_return_sum[e];
-            st_cnt = a.st.done_count[e];
-            st_steps = a.st.done_steps_sum[e];
-        }
-    }
-    // scenario state
-    uint32_t sen_lo = 0, sen_hi = 0, cap_lo = 0, cap_hi = 0;  // PCP prey flags as bit masks (P <= 64)
-    uint8_t loaded = 0;                                      // Warehouse
-    float goal_x = 0.0f, goal_y = 0.0f;                      // Simple
-    uint32_t grid_pre[6] = {0, 0, 0, 0, 0, 0};               // ArcticTransport
-    int goal_col = 1, pix = 0, reached = 0;
-    int load = 0, zone0 = 0, zone1 = 0;                      // MaterialTransport
-    int msg[4] = {0, 0, 0, 0};
-    // PCP: the env's prey block is fetched into registers now (up to PRE floats per lane, i.e.
-    // P <= PRE*GW/2 prey) and put into LDS only when the epilogue needs it, so the load latency
-    // hides behind the sub-step loop; larger P take the direct copy below.
-    constexpr int PRE = 4;
-    float pre[PRE] = {0.0f, 0.0f, 0.0f, 0.0f};
-    static_assert(SCN != RG_SCN_ARCTIC_TRANSPORT || GW == 4, "ArcticTransport is a 4-agent scenario");
-    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-        const int P = p.num_prey;
-        if (env_ok) {
-            if (2 * P <= PRE * GW) {
-#pragma unroll
-                for (int t = 0; t < PRE; ++t)
-                    if (ag + t * GW < 2 * P) pre[t] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + ag + t * GW];
-            } else {
-                for (int i = ag; i < 2 * P; i += GW) lds.prey[g][i] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + i];
-            }
-            for (int i = ag; i < P; i += GW) {
-                const uint32_t sb = a.st.prey_sensed[static_cast<size_t>(e) * P + i] != 0;
-                const uint32_t cb = a.st.prey_captured[static_cast<size_t>(e) * P + i] != 0;
-                if (i < 32) {
-                    sen_lo |= sb << i;
-                    cap_lo |= cb << i;
-                } else {
-                    sen_hi |= sb << (i - 32);
-                    cap_hi |= cb << (i - 32);
-                }
-            }
-        }
-        sen_lo = group_or<GW>(sen_lo);
-        cap_lo = group_or<GW>(cap_lo);
-        if (P > 32) {
-            sen_hi = group_or<GW>(sen_hi);
-            cap_hi = group_or<GW>(cap_hi);
-        }
-    } else if constexpr (SCN == RG_SCN_WAREHOUSE) {
-        if (lane_ok) loaded = a.st.loaded[eN + ag];
-    } else if constexpr (SCN == RG_SCN_SIMPLE) {
-        if (env_ok) {
-            goal_x = a.st.prey_loc[static_cast<size_t>(e) * 2];
-            goal_y = a.st.prey_loc[static_cast<size_t>(e) * 2 + 1];
-        }
-    } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
-        if (env_ok) {
-            // 96 terrain bytes = 24 dwords: 6 per lane of the group (GW = 4)
-            const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(a.st.grid + static_cast<size_t>(e) * 96);
-#pragma unroll
-            for (int t = 0; t < 6; ++t) grid_pre[t] = gsrc[ag * 6 + t];
-            goal_col = a.st.goal_col[e];
-        }
-        if (lane_ok) {
-            pix = a.st.pixel_type[eN + ag];
-            reached = a.st.reached_goal[eN + ag];
-        }
-    } else {
-        if (env_ok) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                msg[i] = a.st.messages[4 * e + i];
-                if constexpr (!OBS_ONLY)
-                    if (i < N) msg[i] = a.actions[eN + i] % 4;  // MaterialTransport.py:119-120
-            }
-            zone0 = a.st.zone_load[2 * e];
-            zone1 = a.st.zone_load[2 * e + 1];
-        }
-        if (lane_ok) load = a.st.load[eN + ag];
-    }
-
-    int viol = 0, max_sweeps = 0;
-    float dist = 0.0f;
-    if constexpr (!OBS_ONLY) {
-#ifdef RG_STAMPS
-        asm volatile("" ::"v"(x), "v"(y), "v"(th), "v"(carry), "v"(act));
-#endif
-        RG_STAMP(0);  // inputs loaded
-        // ---- a1 goal generation (agent.py:48-76, warehouse.py:19-45, MaterialTransport.py:19-46)
-        float gx = x, gy = y;
-        {
-            const int mv = (SCN == RG_SCN_MATERIAL_TRANSPORT) ? act / 4 : act;
-            float sd = agent_step;
-            if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {  // agent.py:89-113: drones 0,1; ice 2; water 3
-                const float nrm_s = p.arctic_normal_step, slow_s = p.arctic_slow_step, fast_s = p.arctic_fast_step;
-                const float water = pix == 1 ? slow_s : pix == 2 ? fast_s : nrm_s;
-                const float ice = pix == 1 ? fast_s : pix == 2 ? slow_s : nrm_s;
-                sd = ag < 2 ? fast_s : ag == 3 ? water : ice;
-            }
-            const float cgx = clamp_spec(gx, p.left, p.right), cgy = clamp_spec(gy, p.up, p.down);
-            const float lft = (gx - sd) > p.left ? (gx - sd) : p.left;
-            const float rgt = (gx + sd) < p.right ? (gx + sd) : p.right;
-            const float upw = (gy - sd) > p.up ? (gy - sd) : p.up;
-            const float dwn = (gy + sd) < p.down ? (gy + sd) : p.down;
-            gx = mv == 0 ? lft : mv == 1 ? rgt : cgx;
-            gy = mv == 2 ? upw : mv == 3 ? dwn : cgy;
-        }
-        // ---- a2 roboEnv.step (utilities/roboEnv.py:52-94), float spec of oracle/oracle_core.h, one
-        // CONTROLLER PERIOD (<= 15 sub-steps with v, w held) at a time: theta and dist_travelled
-        // advance once per period by fma; inside the period only x, y and (cos, sin) move.
-        //
-        // _validate every sub-step: the exact test (GW-1 DPP rounds of float math) runs only in a
-        // rare wave-uniform branch.  The common path is a conservative pre-test (kernel_args.h): the
-        // collision points rounded to binary16 pairs -- per pair round one DPP + v_pk_add_f16 +
-        // v_dot2_f32_f16 -- against a threshold widened by the rounding bound, and one boundary test
-        // per chunk on the chunk's first position widened by the chunk's travel.  Absent lanes /
-        // finished envs sit on far-apart ghost points.  CHUNK sub-steps are advanced and tested
-        // together: their test chains are independent, which is the only ILP a single wavefront has here.
-        const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
-        const int ghost_q = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(1000.0f + 32.0f * ag, -1000.0f));
-        float v = 0.0f, w = 0.0f, s = 0.0f, c = 1.0f;
-        float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
-        bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
-        float fin_x = 0.0f, fin_y = 0.0f;
-        const bool penalize = p.penalize_violations != 0;
-        const int U = p.update_frequency, period = p.controller_period;
-        for (int it0 = 0; it0 < U; it0 += period) {
-            const int n = (U - it0) < period ? (U - it0) : period;
-            sincos_spec(th, s, c);
-            const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w);
-            max_sweeps = sw > max_sweeps ? sw : max_sweeps;
-            const float dtv = k.dt * v, dtw = k.dt * w;
-            float sd, cd;
-            sincos_small_spec(dtw, sd, cd);
-            if (__any(__builtin_fabsf(dtw) > 0.25f)) {  // only with non-rps time steps / velocity limits
-                float sd2, cd2;
-                sincos_spec(dtw, sd2, cd2);
-                const bool big = __builtin_fabsf(dtw) > 0.25f;
-                sd = big ? sd2 : sd;
-                cd = big ? cd2 : cd;
-            }
-            if (it0 == 0) RG_STAMP(1);  // first controller done
-            const float mrg = __builtin_fmaf((CHUNK - 1) * 1.000001f, __builtin_fabsf(dtv), PRE_SLACK);
-            int n_exec = n;             // sub-steps this env executes in this period
-            bool died_now = false;
-
-            // C sub-steps starting at sub-step j0 of this period
-            auto run_chunk = [&](auto CC, int j0) {
-                constexpr int C = decltype(CC)::value;
-                const float x0 = x, y0 = y, c0 = c, s0 = s;
-                const bool live = lane_ok & !dead;
-                int q[C];
-                // every pre-update position of the chunk lies within (C-1)|dt v| of the first
-                const bool bnd_any = live & ((__builtin_fabsf(x - k.xc) + mrg > k.xh) | (__builtin_fabsf(y - k.yc) + mrg > k.yh));
-                static_for<0, C>([&](auto UU) {
-                    constexpr int u = decltype(UU)::value;
-                    const float fx = __builtin_fmaf(k.coll_off, c, x), fy = __builtin_fmaf(k.coll_off, s, y);
-                    const int qr = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(fx, fy));
-                    q[u] = live ? qr : ghost_q;
-                    // Euler step (Appendix A.4); rotate (cos, sin) by dt*w
-                    x = __builtin_fmaf(c, dtv, x);
-                    y = __builtin_fmaf(s, dtv, y);
-                    const float cn = __builtin_fmaf(c, cd, -(s * sd));
-                    const float sn = __builtin_fmaf(s, cd, c * sd);
-                    c = cn;
-                    s = sn;
-                });
-                int dmin = 0x7FFFFFFF;
-                static_for<0, C>([&](auto UU) {
-                    constexpr int u = decltype(UU)::value;
-                    auto test = [&](int partner_q) {
-                        const half2v dq = __builtin_bit_cast(half2v, q[u]) - __builtin_bit_cast(half2v, partner_q);
-                        const int d2 = dot2_bits(dq);
-                        dmin = d2 < dmin ? d2 : dmin;
-                    };
-                    if constexpr (GW == 8 && NT >= 5 && NT <= 7) {
-                        // the pre-test may visit the pairs in any order: the three quad rounds cover the
-                        // pairs inside each quad, then each agent of the upper quad (4 .. N-1) is broadcast
-                        // over its quad and mirrored onto the lower one: 3 + (N-4) rounds instead of 7
-                        static_for<1, 4>([&](auto KK) { test(xor_lane_i<decltype(KK)::value>(q[u])); });
-                        static_for<0, NT - 4>([&](auto MM) {
-                            constexpr int M = decltype(MM)::value;
-                            test(cross_lane_i<M>(q[u]));
-                        });
-                    } else {
-                        static_for<1, GW>([&](auto KK) { test(xor_lane_i<decltype(KK)::value>(q[u])); });
-                    }
-                });
-                if (penalize && __any((dmin <= thr_pre) | bnd_any)) {
-                    // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
-                    float rx = x0, ry = y0, rc = c0, rs = s0;
-                    for (int u = 0; u < C; ++u) {
-                        const bool bnd = lane_ok & !dead & ((rx < k.xmin) | (rx > k.xmax) | (ry < k.ymin) | (ry > k.ymax));
-                        const float fx = __builtin_fmaf(k.coll_off, rc, rx), fy = __builtin_fmaf(k.coll_off, rs, ry);
-                        bool col = false;
-                        if constexpr (GW == 8 && NT >= 5 && NT <= 7) {  // same pair cover as the pre-test: 3 + (N-4) rounds
-                            static_for<1, 4>([&](auto KK) {
-                                constexpr int K = decltype(KK)::value;
-                                const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
-                                col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
-                            });
-                            static_for<0, NT - 4>([&](auto MM) {  // lower lanes meet agent 4+M, upper lanes agent M
-                                constexpr int M = decltype(MM)::value;
-                                const float dx = fx - cross_lane<M>(fx), dy = fy - cross_lane<M>(fy);
-                                col = col | (dx * dx + dy * dy <= k.coll_lim2);
-                            });
-                        } else {
-                            static_for<1, GW>([&](auto KK) {
-                                constexpr int K = decltype(KK)::value;
-                                const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
-                                col = col | (((ag ^ K) < N) & (dx * dx + dy * dy <= k.coll_lim2));
-                            });
-                        }
-                        col = col & lane_ok & !dead;
-                        const int code = (group_any<GW>(col, gbase) ? 1 : 0) | (group_any<GW>(bnd, gbase) ? 2 : 0);
-                        rx = __builtin_fmaf(rc, dtv, rx);  // the violating sub-step is still integrated
-                        ry = __builtin_fmaf(rs, dtv, ry);
-                        if (env_ok & !dead & (code != 0)) {
-                            viol = code;
-                            n_exec = j0 + u + 1;
-                            died_now = true;
-                            dead = true;
-                            fin_x = rx;
-                            fin_y = ry;
-                        }
-                        const float cn = __builtin_fmaf(rc, cd, -(rs * sd));
-                        const float sn = __builtin_fmaf(rs, cd, rc * sd);
-                        rc = cn;
-                        rs = sn;
-                    }
-                }
-            };
-            int j = 0;
-            for (; j + CHUNK <= n; j += CHUNK) run_chunk(std::integral_constant<int, CHUNK>{}, j);
-            static_for<1, CHUNK>([&](auto RR) {  // the remainder as one shorter chunk
-                if (n - j == decltype(RR)::value) run_chunk(RR, j);
-            });
-
-            // period end: heading and distance for the sub-steps this env executed
-            const bool upd = env_ok & (!dead | died_now);
-            const float ne = static_cast<float>(n_exec);
-            const float adv = __builtin_fabsf(dtv);
-            th = upd ? wrap_spec(__builtin_fmaf(ne, dtw, th)) : th;
-            acc = upd ? __builtin_fmaf(ne, adv, acc) : acc;
-            last = upd ? adv : last;
-            if (it0 == 0) RG_STAMP(2);  // first period done
-            if (!__any(env_ok & !dead)) break;
-        }
-        if (dead) {
-            x = fin_x;
-            y = fin_y;
-        }
-        dist = viol ? acc : acc - last;
-        carry = last;
-        RG_STAMP(3);  // all periods done
-    }
-
-    // ---- scenario epilogue
-    const int D = p.obs_dim;
-    float *obs_row = a.io.obs + (eN + ag) * D;
-    bool done = false;
-    int remaining = -1;
-    float reward = 0.0f;
-
-    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-        const int P = p.num_prey;
-        const float sr2 = sr * sr, cr2 = cr * cr;
-        if (2 * P <= PRE * GW) {
-#pragma unroll
-            for (int t = 0; t < PRE; ++t)
-                if (ag + t * GW < 2 * P) lds.prey[g][ag + t * GW] = pre[t];
-        }
-        __syncthreads();  // LDS prey block visible (single-wave workgroup: waitcnt + s_barrier)
-        uint32_t nsen_lo = sen_lo, nsen_hi = sen_hi, ncap_lo = cap_lo, ncap_hi = cap_hi;
-        // The prey block is scanned four at a time (LDS reads in flight together).  scan(lo, hi, f)
-        // calls f(i, prey_x, prey_y, d2) for i in [lo, hi).
-        auto scan = [&](int lo, int hi, auto &&f) {
-            for (int i0 = lo; i0 < hi; i0 += 4) {
-                float2 pl[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int i = (i0 + t) < hi ? (i0 + t) : (hi - 1);
-                    pl[t] = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * i]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float dx = x - pl[t].x, dy = y - pl[t].y;
-                    f(i0 + t, (i0 + t) < hi, pl[t].x, pl[t].y, dx * dx + dy * dy);
-                }
-            }
-        };
-        float closest = -1.0f, qx = -5.0f, qy = -5.0f;
-        if (P <= 8) {
-            // common case (P = 6): the whole prey block in registers, one pass for tracking and
-            // the nearest-prey search, no second trip to LDS
-            float2 pl[8];
-            float d2[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                pl[t] = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * (t < P ? t : P - 1)]);
-            }
-            uint32_t s_b = 0, c_b = 0;
-            const bool acts = lane_ok & (act == 4);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float dx = x - pl[t].x, dy = y - pl[t].y;
-                d2[t] = dx * dx + dy * dy;
-                const bool in = t < P;
-                s_b |= ((in & lane_ok & (d2[t] <= sr2)) ? 1u : 0u) << t;
-                c_b |= ((in & acts & (d2[t] <= cr2)) ? 1u : 0u) << t;
-            }
-            if constexpr (!OBS_ONLY) {  // a11 _update_tracking_and_locations (PredatorCapturePrey.py:72-95)
-                s_b = group_or<GW>(s_b);
-                c_b = group_or<GW>(c_b);
-                nsen_lo = sen_lo | (s_b & ~cap_lo);            // sensed: any agent in range, prey not yet captured
-                ncap_lo = cap_lo | (nsen_lo & c_b & ~cap_lo);  // captured: sensed and a 'no_action' agent in range
-                if (env_ok && ag < P) {
-                    a.st.prey_sensed[static_cast<size_t>(e) * P + ag] = (nsen_lo >> ag) & 1u;
-                    a.st.prey_captured[static_cast<size_t>(e) * P + ag] = (ncap_lo >> ag) & 1u;
-                }
-                if constexpr (GW < 8)
-                    if (env_ok && ag + GW < P) {
-                        a.st.prey_sensed[static_cast<size_t>(e) * P + ag + GW] = (nsen_lo >> (ag + GW)) & 1u;
-                        a.st.prey_captured[static_cast<size_t>(e) * P + ag + GW] = (ncap_lo >> (ag + GW)) & 1u;
-                    }
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {  // a13 nearest uncaptured prey within the agent's own sensing radius
-                const bool cap = ((ncap_lo >> t) & 1u) != 0;
-                const bool take = (t < P) & !cap & (d2[t] <= sr2) & ((d2[t] < closest) | (closest == -1.0f));
-                qx = take ? pl[t].x : qx;
-                qy = take ? pl[t].y : qy;
-                closest = take ? d2[t] : closest;
-            }
-        } else {
-        if constexpr (!OBS_ONLY) {  // a11, general P
-            uint32_t s_lo = 0, s_hi = 0, c_lo = 0, c_hi = 0;  // prey this agent senses / could capture
-            const bool acts = lane_ok & (act == 4);
-            const int P32 = P < 32 ? P : 32;
-            scan(0, P32, [&](int i, bool in, float, float, float d2) {
-                s_lo |= ((in & lane_ok & (d2 <= sr2)) ? 1u : 0u) << (i & 31);
-                c_lo |= ((in & acts & (d2 <= cr2)) ? 1u : 0u) << (i & 31);
-            });
-            s_lo = group_or<GW>(s_lo);
-            c_lo = group_or<GW>(c_lo);
-            nsen_lo = sen_lo | (s_lo & ~cap_lo);
-            ncap_lo = cap_lo | (nsen_lo & c_lo & ~cap_lo);
-            if (P > 32) {
-                scan(32, P, [&](int i, bool in, float, float, float d2) {
-                    s_hi |= ((in & lane_ok & (d2 <= sr2)) ? 1u : 0u) << ((i - 32) & 31);
-                    c_hi |= ((in & acts & (d2 <= cr2)) ? 1u : 0u) << ((i - 32) & 31);
-                });
-                s_hi = group_or<GW>(s_hi);
-                c_hi = group_or<GW>(c_hi);
-                nsen_hi = sen_hi | (s_hi & ~cap_hi);
-                ncap_hi = cap_hi | (nsen_hi & c_hi & ~cap_hi);
-            }
-            if (env_ok) {
-                for (int i = ag; i < P; i += GW) {
-                    const uint32_t sw_ = i < 32 ? nsen_lo >> i : nsen_hi >> (i - 32);
-                    const uint32_t cw_ = i < 32 ? ncap_lo >> i : ncap_hi >> (i - 32);
-                    a.st.prey_sensed[static_cast<size_t>(e) * P + i] = sw_ & 1u;
-                    a.st.prey_captured[static_cast<size_t>(e) * P + i] = cw_ & 1u;
-                }
-            }
-        }
-        {   // a13, general P
-            auto nearest = [&](uint32_t capmask, int base) {
-                return [&, capmask, base](int i, bool in, float px, float py, float d2) {
-                    const bool cap = ((capmask >> ((i - base) & 31)) & 1u) != 0;
-                    const bool take = in & !cap & (d2 <= sr2) & ((d2 < closest) | (closest == -1.0f));
-                    qx = take ? px : qx;
-                    qy = take ? py : qy;
-                    closest = take ? d2 : closest;
-                };
-            };
-            scan(0, P < 32 ? P : 32, nearest(ncap_lo, 0));
-            if (P > 32) scan(32, P, nearest(ncap_hi, 32));
-        }
-        }
-        const int od = p.capability_aware ? 6 : 4;
-        lds.own[lane][0] = x;
-        lds.own[lane][1] = y;
-        lds.own[lane][2] = qx;
-        lds.own[lane][3] = qy;
-        lds.own[lane][4] = sr;
-        lds.own[lane][5] = cr;
-        __syncthreads();
-        if (od == 6) {
-            if (lane_ok) {
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) obs_row[cc] = lds.own[lane][cc];
-            }
-            write_neighbour_obs<GW, 6>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
-        } else {
-            if (lane_ok) *reinterpret_cast<float4 *>(obs_row) = make_float4(x, y, qx, qy);
-            write_neighbour_obs<GW, 4>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
-        }
-        if constexpr (!OBS_ONLY) {  // a14 reward / termination (PredatorCapturePrey.py:155-176, 209-216)
-            const int unseen0 = P - __builtin_popcount(sen_lo) - __builtin_popcount(sen_hi);
-            const int left0 = P - __builtin_popcount(cap_lo) - __builtin_popcount(cap_hi);
-            const int unseen1 = P - __builtin_popcount(nsen_lo) - __builtin_popcount(nsen_hi);
-            const int left1 = P - __builtin_popcount(ncap_lo) - __builtin_popcount(ncap_hi);
-            if (viol) {
-                reward = p.violation_reward;
-                done = true;
-            } else {
-                reward = 0.0f;
-                reward = reward + static_cast<float>(unseen0 - unseen1) * p.sense_reward;
-                reward = reward + static_cast<float>(left0 - left1) * p.capture_reward;
-                reward = reward + p.time_penalty;
-                if (steps > p.max_episode_steps || left1 == 0) {
-                    done = true;
-                    remaining = left1;
-                }
-            }
-        }
-    } else if constexpr (SCN == RG_SCN_WAREHOUSE) {  // a15 (warehouse.py:102-178): obs BEFORE the reward mutates `loaded`
-        lds.own[lane][0] = x;
-        lds.own[lane][1] = y;
-        lds.own[lane][2] = loaded ? 1.0f : 0.0f;
-        __syncthreads();
-        if (lane_ok) {
-            obs_row[0] = x;
-            obs_row[1] = y;
-            obs_row[2] = loaded ? 1.0f : 0.0f;
-        }
-        write_neighbour_obs<GW, 3>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
-        if constexpr (!OBS_ONLY) {
-            if (viol) {
-                reward = p.violation_reward;
-                done = true;
-            } else {
-                const bool green = (ag % 2) == 0;  // warehouse.py:63-65
-                if (loaded) {
-                    if (x < -1.5f + p.goal_width && ((green && y > 0.0f) || (!green && y <= 0.0f))) {
-                        reward = p.unload_reward;
-                        loaded = 0;
-                    }
-                } else {
-                    if (x > 1.5f - p.goal_width && ((!green && y > 0.0f) || (green && y <= 0.0f))) {
-                        reward = p.load_reward;
-                        loaded = 1;
-                    }
-                }
-                done = steps > p.max_episode_steps;
-                if (lane_ok) a.st.loaded[eN + ag] = loaded;
-            }
-        }
-    } else if constexpr (SCN == RG_SCN_SIMPLE) {  // scenarios/Simple/simple.py:155-225
-        lds.own[lane][0] = x;
-        lds.own[lane][1] = y;
-        __syncthreads();
-        if (lane_ok) {
-            obs_row[0] = x;
-            obs_row[1] = y;
-            obs_row[2 * N] = goal_x;
-            obs_row[2 * N + 1] = goal_y;
-        }
-        write_neighbour_obs<GW, 2>(lds, N, N - 1, ag, gbase, lane_ok, x, y, obs_row);  // all others, index order
-        if constexpr (!OBS_ONLY) {
-            if (viol) {
-                reward = p.violation_reward;
-                done = true;
-            } else {
-                const float dx = x - goal_x, dy = y - goal_y;
-                const float r = -(dx * dx + dy * dy);
-                reward = r * p.reward_scaler;
-                done = steps > p.max_episode_steps;
-            }
-        }
-    } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {  // ArcticTransport.py:84-143, agent.py:14-87
-        {
-            uint32_t *gdst = reinterpret_cast<uint32_t *>(&lds.grid[g][0]);
-#pragma unroll
-            for (int t = 0; t < 6; ++t) gdst[ag * 6 + t] = grid_pre[t];
-        }
-        __syncthreads();
-        const uint8_t *grid = &lds.grid[g][0];
-        // get_cell_from_pose: int() truncates toward zero; /0.25 is exact
-        int row = -static_cast<int>((y - 1.0f) / 0.25f), col = static_cast<int>((x + 1.5f) / 0.25f);
-        row = row < 0 ? 0 : row > 7 ? 7 : row;
-        col = col < 0 ? 0 : col > 11 ? 11 : col;
-        if constexpr (!OBS_ONLY) {
-            pix = grid[row * 12 + col];
-            reached = reached | (pix == 3 ? 1 : 0);
-        }
-        const int here = grid[row * 12 + col];
-        lds.own[lane][0] = x;
-        lds.own[lane][1] = y;
-        lds.own[lane][2] = static_cast<float>(here);
-        lds.aload[lane] = row * 16 + col;
-        __syncthreads();
-        const float goalx = static_cast<float>(goal_col) * 0.25f - 1.5f, goaly = -1.0f * 0.25f + 0.75f;
-        if (lane_ok) {
-            obs_row[0] = x;
-            obs_row[1] = y;
-            obs_row[2] = static_cast<float>(here);
-            // the other three in the order of agent.py:42-69: {1,2,3} {0,2,3} {3,0,1} {2,0,1}
-            const int o0 = ag == 0 ? 1 : ag == 1 ? 0 : ag == 2 ? 3 : 2;
-            const int o1 = ag < 2 ? 2 : 0, o2 = ag < 2 ? 3 : 1;
-            const int oth[3] = {o0, o1, o2};
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                obs_row[3 + 3 * m + 0] = lds.own[gbase + oth[m]][0];
-                obs_row[3 + 3 * m + 1] = lds.own[gbase + oth[m]][1];
-                obs_row[3 + 3 * m + 2] = lds.own[gbase + oth[m]][2];
-            }
-            obs_row[12] = goalx;
-            obs_row[13] = goaly;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {  // the 8 cells around each drone, edges clamped
-                const int rc = lds.aload[gbase + i];
-                const int r_ = rc >> 4, c_ = rc & 15;
-                const int left = c_ > 0 ? c_ - 1 : c_, right = c_ < 11 ? c_ + 1 : c_;
-                const int up = r_ > 0 ? r_ - 1 : r_, down = r_ < 7 ? r_ + 1 : r_;
-                float *o = obs_row + 14 + 8 * i;
-                o[0] = static_cast<float>(grid[up * 12 + left]);
-                o[1] = static_cast<float>(grid[r_ * 12 + left]);
-                o[2] = static_cast<float>(grid[down * 12 + left]);
-                o[3] = static_cast<float>(grid[up * 12 + c_]);
-                o[4] = static_cast<float>(grid[down * 12 + c_]);
-                o[5] = static_cast<float>(grid[up * 12 + right]);
-                o[6] = static_cast<float>(grid[r_ * 12 + right]);
-                o[7] = static_cast<float>(grid[down * 12 + right]);
-            }
-        }
-        if constexpr (!OBS_ONLY) {
-            // shared reward over the two ground robots, in agent order (ArcticTransport.py:125-134)
-            const float dx = x - goalx, dy = y - goaly;
-            lds.ax[lane] = dx * dx + dy * dy;
-            lds.ay[lane] = static_cast<float>(pix * 2 + reached);
-            __syncthreads();
-            if (viol) {
-                reward = p.violation_reward;
-                done = true;
-            } else {
-                reward = 0.0f;
-                bool all_reached = true;
-#pragma unroll
-                for (int j = 2; j < 4; ++j) {
-                    const int pr = static_cast<int>(lds.ay[gbase + j]);
-                    const bool rj = (pr & 1) != 0;
-                    if (!rj) reward = reward + p.not_reached_penalty;
-                    if ((pr >> 1) != 3) reward = reward + p.dist_multiplier * lds.ax[gbase + j];
-                    all_reached = all_reached && rj;
-                }
-                done = steps > p.max_episode_steps;
-                if (!done) done = all_reached;
-            }
-            if (lane_ok) {
-                a.st.pixel_type[eN + ag] = static_cast<uint8_t>(pix);
-                a.st.reached_goal[eN + ag] = static_cast<uint8_t>(reached);
-            }
-        }
-    } else {  // a16 MaterialTransport (MaterialTransport.py:113-189)
-        if (lane_ok) {
-            obs_row[0] = x;
-            obs_row[1] = y;
-            obs_row[2] = static_cast<float>(load);
-            obs_row[3] = static_cast<float>(zone0);
-            obs_row[4] = static_cast<float>(zone1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) obs_row[5 + i] = static_cast<float>(msg[i]);
-            if (p.capability_aware) {
-                obs_row[9] = static_cast<float>(p.torque[ag]);
-                obs_row[10] = agent_step;
-            }
-        }
-        if constexpr (!OBS_ONLY) {
-            lds.ax[lane] = x;
-            lds.ay[lane] = y;
-            lds.aload[lane] = load;
-            __syncthreads();
-            if (viol) {
-                reward = p.violation_reward;
-                done = true;
-            } else {
-                // zone depletion is order-dependent across agents (MaterialTransport.py:161-189):
-                // every lane replays the env's sequential loop from the LDS copy
-                reward = p.time_penalty;
-                const float egw = p.end_goal_width;
-                const float zr2 = p.zone1_radius * p.zone1_radius;
-                bool any_load = false;
-                for (int j = 0; j < N; ++j) {
-                    const float jx = lds.ax[gbase + j], jy = lds.ay[gbase + j];
-                    int jl = lds.aload[gbase + j];
-                    const int tq = p.torque[j];
-                    if (jl > 0) {
-                        if (jx < -1.5f + egw) {
-                            reward = reward + static_cast<float>(jl) * p.unload_multiplier;
-                            jl = 0;
-                        }
-                    } else {
-                        if (jx > 1.5f - egw) {
-                            if (zone1 > tq) {
-                                jl = tq;
-                                zone1 -= tq;
-                            } else {
-                                jl = zone1;
-                                zone1 = 0;
-                            }
-                            reward = reward + static_cast<float>(jl) * p.load_multiplier;
-                        } else if (jx * jx + jy * jy <= zr2) {
-                            if (zone0 > tq) {
-                                jl = tq;
-                                zone0 -= tq;
-                            } else {
-                                jl = zone0;
-                                zone0 = 0;
-                            }
-                            reward = reward + static_cast<float>(jl) * p.load_multiplier;
-                        }
-                    }
-                    if (j == ag) load = jl;
-                    any_load = any_load || (jl != 0);
-                }
-                done = steps > p.max_episode_steps;
-                if (!done) done = (zone0 == 0 && zone1 == 0 && !any_load);
-            }
-            int total = 0;
-            {   // info['remaining'] = zone loads + agent loads (after the update)
-                lds.aload[lane] = lane_ok ? load : 0;
-                __syncthreads();
-                for (int j = 0; j < N; ++j) total += lds.aload[gbase + j];
-            }
-            if (done) remaining = zone0 + zone1 + total;
-            if (lane_ok) a.st.load[eN + ag] = load;
-            if (lane_ok && ag == 0) {
-                a.st.zone_load[2 * e] = zone0;
-                a.st.zone_load[2 * e + 1] = zone1;
-            }
-            if (lane_ok && ag < 4) a.st.messages[4 * e + ag] = msg[ag == 0 ? 0 : ag == 1 ? 1 : ag == 2 ? 2 : 3];
-        }
-    }
-
-    RG_STAMP(4);  // scenario epilogue computed
-    if constexpr (!OBS_ONLY) {
-        // sum of the agents' rewards in agent order (only read when shared_reward == 0)
-        float rsum = 0.0f;
-        if (stats && !p.shared_reward) {
-            __syncthreads();
-            lds.ax[lane] = lane_ok ? reward : 0.0f;
-            __syncthreads();
-            for (int j = 0; j < N; ++j) rsum = rsum + lds.ax[gbase + j];
-        }
-        // ---- stores
-        if (lane_ok) {
-            float *X = a.st.poses + eN * 3;
-            X[ag] = x;
-            X[N + ag] = y;
-            X[2 * N + ag] = th;
-            a.st.carry_dist[eN + ag] = carry;
-            a.io.reward[eN + ag] = reward;
-            a.io.dist_travelled[eN + ag] = dist;
-            if (ag == 0) {
-                a.st.episode_steps[e] = steps;
-                if (stats) {  // misc.py:178-185: episodeReward += reward[0] | sum(reward)
-                    float ret = st_ret + (p.shared_reward ? reward : rsum);
-                    if (done) {
-                        a.st.done_return_sum[e] = st_sum + ret;
-                        a.st.done_count[e] = st_cnt + 1;
-                        a.st.done_steps_sum[e] = st_steps + steps;
-                        ret = 0.0f;
-                    }
-                    a.st.ep_return[e] = ret;
-                }
-                a.io.done[e] = done ? 1 : 0;
-                a.io.violation[e] = static_cast<uint8_t>(viol);
-                a.io.remaining[e] = remaining;
-                if (a.io.qp_sweeps) a.io.qp_sweeps[e] = max_sweeps;
-            }
-        }
-        RG_STAMP(5);  // outputs stored
-        // ---- fused auto-reset of finished envs (scenario.reset(); ~1 env in 70 per step)
-        if (a.auto_reset && __any(env_ok & done)) {
-            __syncthreads();  // the wave's state stores are issued before the resetting lanes rewrite them
-            reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done);
-        }
-        RG_STAMP(6);  // reset done
-#ifdef RG_STAMPS
-        if (lane == 0 && a.io.qp_sweeps) {
-            stamps[7] = max_sweeps;
-            for (int i = 0; i < 8; ++i)
-                if (blockIdx.x * EPW + i < a.E) a.io.qp_sweeps[blockIdx.x * EPW + i] = stamps[i];
-        }
-#endif
-    }
-}
-
-template <int SCN, int GW>
-__global__ __launch_bounds__(WAVE) void reset_kernel(const KernelArgs a) {
-    constexpr int EPW = WAVE / GW;
-    __shared__ Lds<GW> lds;
-    const int lane = threadIdx.x;
-    const int ag = lane & (GW - 1);
-    const int g = lane / GW;
-    const int e = blockIdx.x * EPW + g;
-    const bool env_ok = e < a.E;
-    const bool want = env_ok && (a.reset_mask == nullptr || a.reset_mask[e] != 0);
-    if (!__any(want)) return;
-    reset_group<SCN, GW>(a, lds, e, g, ag, want);
-}
-
-}  // namespace rg
-
-// ------------------------------------------------------------------ host side: launch dispatch
-namespace rg {
-
-static int group_width(int N) { return N <= 4 ? 4 : N <= 8 ? 8 : 16; }
-
-template <int SCN, bool OBS_ONLY>
-static hipError_t launch_step_scn(const KernelArgs &a, hipStream_t stream) {
-    const int gw = group_width(a.p.n_agents);
-    const int grid = (a.E + WAVE / gw - 1) / (WAVE / gw);
-    if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else if (gw == 16) hipLaunchKernelGGL((step_kernel<SCN, 16, OBS_ONLY>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else if constexpr (OBS_ONLY) hipLaunchKernelGGL((step_kernel<SCN, 8, true>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else if (a.p.n_agents == 5) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 5>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else if (a.p.n_agents == 6) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 6>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else if (a.p.n_agents == 7) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 7>), dim3(grid), dim3(WAVE), 0, stream, a);
-    else hipLaunchKernelGGL((step_kernel<SCN, 8, false, 8>), dim3(grid), dim3(WAVE), 0, stream, a);
-    return hipGetLastError();
-}
 
 template <int SCN>
 static hipError_t launch_reset_scn(const KernelArgs &a, hipStream_t stream) {
@@ -1027,30 +15,7 @@ static hipError_t launch_reset_scn(const KernelArgs &a, hipStream_t stream) {
 }
 
 hipError_t launch_step(const KernelArgs &a, bool obs_only, hipStream_t stream) {
-    switch (a.p.scenario) {
-        case RG_SCN_PREDATOR_CAPTURE_PREY:
-            return obs_only ? launch_step_scn<RG_SCN_PREDATOR_CAPTURE_PREY, true>(a, stream)
-                            : launch_step_scn<RG_SCN_PREDATOR_CAPTURE_PREY, false>(a, stream);
-        case RG_SCN_WAREHOUSE:
-            return obs_only ? launch_step_scn<RG_SCN_WAREHOUSE, true>(a, stream)
-                            : launch_step_scn<RG_SCN_WAREHOUSE, false>(a, stream);
-        case RG_SCN_MATERIAL_TRANSPORT:
-            return obs_only ? launch_step_scn<RG_SCN_MATERIAL_TRANSPORT, true>(a, stream)
-                            : launch_step_scn<RG_SCN_MATERIAL_TRANSPORT, false>(a, stream);
-        case RG_SCN_SIMPLE:
-            return obs_only ? launch_step_scn<RG_SCN_SIMPLE, true>(a, stream)
-                            : launch_step_scn<RG_SCN_SIMPLE, false>(a, stream);
-        case RG_SCN_ARCTIC_TRANSPORT: {
-            const int grid = (a.E + 15) / 16;
-            if (obs_only)
-                hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, true>), dim3(grid), dim3(WAVE), 0, stream, a);
-            else
-                hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false>), dim3(grid), dim3(WAVE), 0, stream, a);
-            return hipGetLastError();
-        }
-        default:
-            return hipErrorInvalidValue;
-    }
+    return obs_only ? launch_step_group<true, false>(a, stream) : launch_step_group<false, false>(a, stream);
 }
 
 hipError_t launch_reset(const KernelArgs &a, hipStream_t stream) {

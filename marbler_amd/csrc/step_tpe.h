@@ -1,0 +1,859 @@
+// step_tpe.h -- the env-step kernel, THREAD-PER-ENV mapping (gfx950 / MI355X, CDNA4).
+// (Templates only; instantiated by robogym_tpe.hip for rg_step and robogym_rollout_tpe.hip for rg_rollout.)
+//
+// Same arithmetic, same outputs, bit for bit, as the lane-group kernel of robogym_kernels.hip
+// (both reproduce the float spec of oracle/oracle_core.h); only the mapping differs:
+//
+//   lane-group kernel : GW lanes per env, one lane per agent, pair work by DPP rounds.  Shortest
+//                       chain for a handful of envs (E < ~1k), but 3 of 8 lanes idle at N = 5, every
+//                       pair is computed on both of its lanes, and group-uniform work runs on every
+//                       lane: ~8 800 lane-instructions per agent-step.
+//   thread-per-env    : one lane owns a whole env; all N agents and N(N-1)/2 pairs live in that
+//     (this file)       lane's registers (N is a template parameter, every loop is unrolled, every
+//                       array index is a compile-time constant).  No cross-lane traffic at all, each
+//                       pair computed once, N independent agent chains per lane for ILP:
+//                       ~1 600 lane-instructions per agent-step.  One wave = 64 envs.
+//
+// With one wave per SIMD up to 65 536 envs the launch time is flat (one wave's chain), beyond that
+// the kernel is VALU-issue bound.  Registers are not a constraint at <= 1 wave per SIMD (512 VGPRs).
+// The host picks this kernel for N <= 8 and E >= RG_TPE_MIN_ENVS (robogym_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "device_common.h"
+
+namespace rg {
+namespace tpe {
+
+constexpr int CH = 5;  // sub-steps per validated chunk (controller periods of 15 and 14 sub-steps: 5+5+5, 5+5+4)
+
+template <int I, int END, typename F>
+__device__ __forceinline__ void sfor(F &&f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, END>(f);
+    }
+}
+
+template <int N>
+constexpr int group_width() {
+    return N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : 16;
+}
+
+// visits the unordered pairs (i, j), i < j < N, in the XOR 1-factorisation order of the spec
+// (k = 1..GW-1, i ascending, j = i ^ k): f(integral_constant i, integral_constant j)
+template <int N, typename F>
+__device__ __forceinline__ void for_pairs(F &&f) {
+    constexpr int GW = group_width<N>();
+    sfor<1, GW>([&](auto KK) {
+        constexpr int K = decltype(KK)::value;
+        sfor<0, N>([&](auto II) {
+            constexpr int I = decltype(II)::value;
+            constexpr int J = I ^ K;
+            if constexpr (I < J && J < N) f(II, std::integral_constant<int, J>{});
+        });
+    });
+}
+
+// ------------------------------------------------------------------ controller (a3..a8)
+template <int N>
+__device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, const float (&x)[N],
+                                          const float (&y)[N], const float (&c)[N], const float (&s)[N],
+                                          const float (&gx)[N], const float (&gy)[N], float (&v)[N], float (&w)[N]) {
+    float xix[N], xiy[N], ux[N], uy[N], uhx[N], uhy[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {  // a4 uni_to_si_states, a5 si_position_controller
+        xix[a] = x[a] + k.pd * c[a];
+        xiy[a] = y[a] + k.pd * s[a];
+        float dx = gx[a] - xix[a], dy = gy[a] - xiy[a];
+        const float nrm = norm2_spec(dx, dy);
+        const float sc = k.pvl / nrm;
+        const bool clip = nrm > k.pvl;
+        ux[a] = clip ? dx * sc : dx;
+        uy[a] = clip ? dy * sc : dy;
+    }
+    // a6 barrier certificate (oracle/oracle_core.h barrier_qp): pair constants
+    const float bgain = p.barrier_gain, ugain = p.unsafe_barrier_gain, qp_rtol = p.qp_rtol;
+    const int qp_cap = p.qp_max_sweeps;
+    const bool has_unsafe = p.barrier_has_unsafe_gain != 0;
+    float ex[N][N], ey[N][N], fx[N][N], fy[N][N], bp[N][N], emax[N][N], mu[N][N], muA[N][N], muB[N][N];
+    for_pairs<N>([&](auto II, auto JJ) {
+        constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
+        const float dx = xix[i] - xix[j], dy = xiy[i] - xiy[j];
+        const float ee = dx * dx + dy * dy;
+        const float h = ee - k.r2;
+        const float gain = ((h >= 0.0f) | !has_unsafe) ? bgain : ugain;
+        const float b = gain * ((h * h) * h);
+        const float n2 = 2.0f * ee;
+        const bool ok = n2 > 0.0f;
+        const float rn2 = ok ? 1.0f / n2 : 0.0f;
+        ex[i][j] = dx;
+        ey[i][j] = dy;
+        fx[i][j] = dx * rn2;
+        fy[i][j] = dy * rn2;
+        bp[i][j] = (0.5f * b) * rn2;
+        emax[i][j] = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
+        mu[i][j] = muA[i][j] = muB[i][j] = 0.0f;
+    });
+#pragma unroll
+    for (int a = 0; a < N; ++a) {  // "Threshold control inputs before QP", decided on squares
+        const float n2u = ux[a] * ux[a] + uy[a] * uy[a];
+        if (n2u > k.bml * k.bml) {
+            const float sc = k.bml / __builtin_sqrtf(n2u);
+            ux[a] = ux[a] * sc;
+            uy[a] = uy[a] * sc;
+        }
+        uhx[a] = ux[a];
+        uhy[a] = uy[a];
+    }
+    int sweeps = 0;
+    bool active = true;
+    auto sweep = [&](auto PH) {
+        constexpr int PHASE = decltype(PH)::value;
+        float chg = 0.0f;
+        for_pairs<N>([&](auto II, auto JJ) {
+            constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
+            const float c0 = mu[i][j] - bp[i][j];
+            const float t = __builtin_fmaf(fy[i][j], uy[j] - uy[i], c0);
+            float mn = __builtin_fmaf(fx[i][j], ux[j] - ux[i], t);
+            mn = (mn > 0.0f) ? mn : 0.0f;
+            const float delta = mn - mu[i][j];
+            mu[i][j] = mn;
+            ux[i] = __builtin_fmaf(delta, ex[i][j], ux[i]);
+            uy[i] = __builtin_fmaf(delta, ey[i][j], uy[i]);
+            ux[j] = __builtin_fmaf(-delta, ex[i][j], ux[j]);
+            uy[j] = __builtin_fmaf(-delta, ey[i][j], uy[j]);
+            chg = fmaxf(chg, __builtin_fabsf(delta) * emax[i][j]);
+            if constexpr (PHASE == 1) muA[i][j] = mn;
+            if constexpr (PHASE == 2) muB[i][j] = mn;
+        });
+        ++sweeps;
+        float umax = k.bml;
+#pragma unroll
+        for (int a = 0; a < N; ++a) umax = fmaxf(umax, fmaxf(__builtin_fabsf(ux[a]), __builtin_fabsf(uy[a])));
+        active = (chg > qp_rtol * umax) & (sweeps < qp_cap);
+        if constexpr (PHASE == 3) {
+            if (active) {  // Aitken restart of the multipliers; u rebuilt agent by agent in round order
+                for_pairs<N>([&](auto II, auto JJ) {
+                    constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
+                    const float d1 = muB[i][j] - muA[i][j], d2 = mu[i][j] - muB[i][j];
+                    const bool geo = (d1 != 0.0f) & (d2 != 0.0f) & ((d1 > 0.0f) == (d2 > 0.0f)) &
+                                     (__builtin_fabsf(d2) < 0.97f * __builtin_fabsf(d1)) & (emax[i][j] > 0.0f);
+                    float m = mu[i][j] - (d2 * d2) / (d2 - d1);
+                    m = (m > 0.0f) ? m : 0.0f;
+                    mu[i][j] = geo ? m : mu[i][j];
+                });
+                constexpr int GW = group_width<N>();
+                sfor<0, N>([&](auto AA) {
+                    constexpr int a = decltype(AA)::value;
+                    float sx = uhx[a], sy = uhy[a];
+                    sfor<1, GW>([&](auto KK) {
+                        constexpr int q = a ^ decltype(KK)::value;
+                        if constexpr (q < N) {
+                            constexpr int lo = a < q ? a : q, hi = a < q ? q : a;
+                            // absent pairs (emax == 0) carry mu == 0: adding 0 * e is exact
+                            const float sgx = a < q ? ex[lo][hi] : -ex[lo][hi], sgy = a < q ? ey[lo][hi] : -ey[lo][hi];
+                            if (emax[lo][hi] > 0.0f) {
+                                sx = __builtin_fmaf(mu[lo][hi], sgx, sx);
+                                sy = __builtin_fmaf(mu[lo][hi], sgy, sy);
+                            }
+                        }
+                    });
+                    ux[a] = sx;
+                    uy[a] = sy;
+                });
+            }
+        }
+    };
+    while (active) {
+        sweep(std::integral_constant<int, 1>{});
+        if (!active) break;
+        sweep(std::integral_constant<int, 2>{});
+        if (!active) break;
+        sweep(std::integral_constant<int, 3>{});
+        if (!active) break;
+        sweep(std::integral_constant<int, 0>{});
+    }
+#pragma unroll
+    for (int a = 0; a < N; ++a) {  // a7 si_to_uni_dyn, a8 set_velocities
+        float vv = c[a] * ux[a] + s[a] * uy[a];
+        float ww = k.inv_pd * (-s[a] * ux[a] + c[a] * uy[a]);
+        ww = ww > k.wlim ? k.wlim : ww;
+        ww = ww < -k.wlim ? -k.wlim : ww;
+        vv = vv > k.vmax ? k.vmax : vv;
+        vv = vv < -k.vmax ? -k.vmax : vv;
+        ww = ww > k.wmax ? k.wmax : ww;
+        ww = ww < -k.wmax ? -k.wmax : ww;
+        v[a] = vv;
+        w[a] = ww;
+    }
+    return sweeps;
+}
+
+// ------------------------------------------------------------------ neighbour rows
+// obs slots 1..K of agent A from the own-observation rows of the K nearest others (ascending
+// squared distance, ties -> lower index); K >= N-1: all others in index order.
+template <int N, int OD, int A>
+__device__ __forceinline__ void write_neighbours(const float (&x)[N], const float (&y)[N], const float (&own)[N][OD],
+                                                 int Knb, float *obs_row) {
+    unsigned long long key[N];
+    int rank[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float dx = x[j] - x[A], dy = y[j] - y[A];
+        key[j] = (static_cast<unsigned long long>(__builtin_bit_cast(unsigned int, dx * dx + dy * dy)) << 32) |
+                 static_cast<unsigned int>(j);
+        rank[j] = 0;
+    }
+    const bool all_others = Knb >= N - 1;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int q = 0; q < j; ++q) {
+            if (j == A || q == A) continue;
+            const int q_first = key[q] < key[j] ? 1 : 0;
+            rank[j] += q_first;
+            rank[q] += 1 - q_first;
+        }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (j == A) continue;
+        const int slot = all_others ? (j < A ? j : j - 1) : rank[j];
+        if (all_others | (slot < Knb)) {
+            float *o = obs_row + (slot + 1) * OD;
+            if constexpr (OD == 4) {
+                *reinterpret_cast<float4 *>(o) = make_float4(own[j][0], own[j][1], own[j][2], own[j][3]);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < OD; ++cc) o[cc] = own[j][cc];
+            }
+        }
+    }
+}
+
+template <int N, int OD>
+__device__ __forceinline__ void write_obs_with_neighbours(const float (&x)[N], const float (&y)[N],
+                                                          const float (&own)[N][OD], int Knb, float *obs_env, int D) {
+    sfor<0, N>([&](auto AA) {
+        constexpr int A = decltype(AA)::value;
+        float *row = obs_env + A * D;
+        if constexpr (OD == 4) {
+            *reinterpret_cast<float4 *>(row) = make_float4(own[A][0], own[A][1], own[A][2], own[A][3]);
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < OD; ++cc) row[cc] = own[A][cc];
+        }
+        write_neighbours<N, OD, A>(x, y, own, Knb, row);
+    });
+}
+
+// ------------------------------------------------------------------ one env step on one lane
+// returns whether the episode ended (roboEnv.py:38-96 + the scenario's step())
+template <int SCN, int N>
+__device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv, const int e) {
+    const rg_scenario_params &p = a.p;
+    const Consts &k = a.k;
+    const size_t eN = static_cast<size_t>(e) * N;
+
+    // ---- loads
+    float x[N], y[N], th[N], acc[N], last[N];
+    int act[N];
+    {
+        const float *X = a.st.poses + eN * 3;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            x[i] = X[i];
+            y[i] = X[N + i];
+            th[i] = X[2 * N + i];
+            acc[i] = a.st.carry_dist[eN + i];  // dist incl. the pending sub-step
+            last[i] = 0.0f;
+            act[i] = sv.actions[eN + i];
+        }
+    }
+    const int steps = a.st.episode_steps[e] + 1;
+    const bool stats = a.st.ep_return != nullptr;
+    float st_ret = 0.0f, st_sum = 0.0f;
+    int st_cnt = 0, st_steps = 0;
+    if (stats) {
+        st_ret = a.st.ep_return[e];
+        st_sum = a.st.done_return_sum[e];
+        st_cnt = a.st.done_count[e];
+        st_steps = a.st.done_steps_sum[e];
+    }
+    int pix[N];
+    if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) pix[i] = a.st.pixel_type[eN + i];
+    }
+
+    // ---- a1 goal generation
+    float gx[N], gy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int mv = (SCN == RG_SCN_MATERIAL_TRANSPORT) ? act[i] / 4 : act[i];
+        float sd = p.agent_step[i];
+        if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+            const float nrm_s = p.arctic_normal_step, slow_s = p.arctic_slow_step, fast_s = p.arctic_fast_step;
+            const float water = pix[i] == 1 ? slow_s : pix[i] == 2 ? fast_s : nrm_s;
+            const float ice = pix[i] == 1 ? fast_s : pix[i] == 2 ? slow_s : nrm_s;
+            sd = i < 2 ? fast_s : i == 3 ? water : ice;
+        }
+        const float cgx = clamp_spec(x[i], p.left, p.right), cgy = clamp_spec(y[i], p.up, p.down);
+        const float lft = (x[i] - sd) > p.left ? (x[i] - sd) : p.left;
+        const float rgt = (x[i] + sd) < p.right ? (x[i] + sd) : p.right;
+        const float upw = (y[i] - sd) > p.up ? (y[i] - sd) : p.up;
+        const float dwn = (y[i] + sd) < p.down ? (y[i] + sd) : p.down;
+        gx[i] = mv == 0 ? lft : mv == 1 ? rgt : cgx;
+        gy[i] = mv == 2 ? upw : mv == 3 ? dwn : cgy;
+    }
+
+    // ---- a2 roboEnv.step, one controller period at a time (float spec of oracle/oracle_core.h)
+    int viol = 0, max_sweeps = 0;
+#ifdef RG_TPE_DIAG
+    int diag = 0, diag_chunk = 0;
+#endif
+    const bool penalize = p.penalize_violations != 0;
+    const int U = p.update_frequency, period = p.controller_period;
+    const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
+    float v[N], w[N], s[N], c[N];
+    for (int it0 = 0; it0 < U && !viol; it0 += period) {
+        const int n = (U - it0) < period ? (U - it0) : period;
+#pragma unroll
+        for (int i = 0; i < N; ++i) sincos_spec(th[i], s[i], c[i]);
+        const int sw = controller<N>(p, k, x, y, c, s, gx, gy, v, w);
+        max_sweeps = sw > max_sweeps ? sw : max_sweeps;
+#ifdef RG_TPE_DIAG
+        diag |= sw << (it0 == 0 ? 8 : 0);
+#endif
+        float dtv[N], dtw[N], sd[N], cd[N], mrg[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            dtv[i] = k.dt * v[i];
+            dtw[i] = k.dt * w[i];
+            mrg[i] = __builtin_fmaf((CH - 1) * 1.000001f, __builtin_fabsf(dtv[i]), PRE_SLACK);
+            if (__builtin_fabsf(dtw[i]) <= 0.25f) sincos_small_spec(dtw[i], sd[i], cd[i]);
+            else sincos_spec(dtw[i], sd[i], cd[i]);
+        }
+        int n_exec = n;
+        // exact _validate on the current (pre-update) poses: bit 0 collision, bit 1 boundary
+        auto validate = [&](const float (&vx)[N], const float (&vy)[N], const float (&vc)[N], const float (&vs)[N]) {
+            int code = 0;
+            float fx[N], fy[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if ((vx[i] < k.xmin) | (vx[i] > k.xmax) | (vy[i] < k.ymin) | (vy[i] > k.ymax)) code |= 2;
+                fx[i] = __builtin_fmaf(k.coll_off, vc[i], vx[i]);
+                fy[i] = __builtin_fmaf(k.coll_off, vs[i], vy[i]);
+            }
+            for_pairs<N>([&](auto II, auto JJ) {
+                constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
+                const float dx = fx[i] - fx[j], dy = fy[i] - fy[j];
+                if (dx * dx + dy * dy <= k.coll_lim2) code |= 1;
+            });
+            return code;
+        };
+        auto advance = [&](float (&ax)[N], float (&ay)[N], float (&ac)[N], float (&as)[N]) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                ax[i] = __builtin_fmaf(ac[i], dtv[i], ax[i]);
+                ay[i] = __builtin_fmaf(as[i], dtv[i], ay[i]);
+                const float cn = __builtin_fmaf(ac[i], cd[i], -(as[i] * sd[i]));
+                const float sn = __builtin_fmaf(as[i], cd[i], ac[i] * sd[i]);
+                ac[i] = cn;
+                as[i] = sn;
+            }
+        };
+        // C sub-steps starting at sub-step j0; returns false when the env hit a violation
+        auto run_chunk = [&](auto CC, int j0) -> bool {
+            constexpr int C = decltype(CC)::value;
+            float x0[N], y0[N], c0[N], s0[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                x0[i] = x[i];
+                y0[i] = y[i];
+                c0[i] = c[i];
+                s0[i] = s[i];
+            }
+            // conservative pre-tests (kernel_args.h): one boundary test per chunk on its first positions
+            // widened by the chunk's travel; per sub-step the collision points rounded to binary16 pairs
+            int dmin = 0x7FFFFFFF;
+            float bmax_x = 0.0f, bmax_y = 0.0f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                bmax_x = fmaxf(bmax_x, __builtin_fabsf(x[i] - k.xc) + mrg[i]);
+                bmax_y = fmaxf(bmax_y, __builtin_fabsf(y[i] - k.yc) + mrg[i]);
+            }
+            const bool bnd_any = (bmax_x > k.xh) | (bmax_y > k.yh);
+            sfor<0, C>([&](auto UU) {
+                half2v q[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    q[i] = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(k.coll_off, c[i], x[i]), __builtin_fmaf(k.coll_off, s[i], y[i])));
+                for_pairs<N>([&](auto II, auto JJ) {
+                    constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
+                    const half2v dq = q[i] - q[j];
+                    const int d2 = dot2_bits(dq);
+                    dmin = d2 < dmin ? d2 : dmin;
+                });
+                advance(x, y, c, s);
+            });
+            if (penalize && ((dmin <= thr_pre) | bnd_any)) {
+#ifdef RG_TPE_DIAG
+                diag |= 1 << (16 + (it0 ? 3 : 0) + j0 / CH);
+#endif
+                // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    x[i] = x0[i];
+                    y[i] = y0[i];
+                    c[i] = c0[i];
+                    s[i] = s0[i];
+                }
+                for (int u = 0; u < C; ++u) {
+                    const int code = validate(x, y, c, s);
+                    advance(x, y, c, s);  // the violating sub-step is still integrated
+                    if (code) {
+                        viol = code;
+                        n_exec = j0 + u + 1;
+                        return false;
+                    }
+                }
+            }
+            return true;
+        };
+        int j = 0;
+        bool ok = true;
+        for (; ok && j + CH <= n; j += CH) ok = run_chunk(std::integral_constant<int, CH>{}, j);
+        sfor<1, CH>([&](auto RR) {  // the remainder as one shorter chunk
+            if (ok && n - j == decltype(RR)::value) ok = run_chunk(RR, j);
+        });
+        // period end: heading and distance for the sub-steps this env executed
+        const float ne = static_cast<float>(n_exec);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float adv = __builtin_fabsf(dtv[i]);
+            th[i] = wrap_spec(__builtin_fmaf(ne, dtw[i], th[i]));
+            acc[i] = __builtin_fmaf(ne, adv, acc[i]);
+            last[i] = adv;
+        }
+    }
+    float dist[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) dist[i] = viol ? acc[i] : acc[i] - last[i];
+
+    // ---- scenario epilogue
+    const int D = p.obs_dim;
+    float *obs_env = sv.io.obs + eN * D;
+    bool done = false;
+    int remaining = -1;
+    float reward[N];
+
+    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
+        const int P = p.num_prey;
+        const float *pl = a.st.prey_loc + static_cast<size_t>(e) * 2 * P;
+        uint8_t *sen = a.st.prey_sensed + static_cast<size_t>(e) * P, *cap = a.st.prey_captured + static_cast<size_t>(e) * P;
+        float sr2[N], cr2[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            sr2[i] = p.sensing_radius[i] * p.sensing_radius[i];
+            cr2[i] = p.capture_radius[i] * p.capture_radius[i];
+        }
+        int unseen0 = 0, left0 = 0, unseen1 = 0, left1 = 0;
+        float closest[N], qx[N], qy[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            closest[i] = -1.0f;
+            qx[i] = -5.0f;
+            qy[i] = -5.0f;
+        }
+        for (int q = 0; q < P; ++q) {  // a11 tracking + a13 nearest prey, prey by prey (PredatorCapturePrey.py:72-95)
+            const float px = pl[2 * q], py = pl[2 * q + 1];
+            bool sensed = sen[q] != 0, captured = cap[q] != 0;
+            unseen0 += !sensed;
+            left0 += !captured;
+            float d2[N];
+            bool any_s = false, any_c = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float dx = x[i] - px, dy = y[i] - py;
+                d2[i] = dx * dx + dy * dy;
+                any_s = any_s | (d2[i] <= sr2[i]);
+                any_c = any_c | ((act[i] == 4) & (d2[i] <= cr2[i]));
+            }
+            if (!captured) {
+                if (!sensed && any_s) sensed = true;
+                if (sensed && any_c) captured = true;
+            }
+            sen[q] = sensed;
+            cap[q] = captured;
+            unseen1 += !sensed;
+            left1 += !captured;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool take = !captured & (d2[i] <= sr2[i]) & ((d2[i] < closest[i]) | (closest[i] == -1.0f));
+                qx[i] = take ? px : qx[i];
+                qy[i] = take ? py : qy[i];
+                closest[i] = take ? d2[i] : closest[i];
+            }
+        }
+        if (p.capability_aware) {
+            float own[N][6];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                own[i][0] = x[i];
+                own[i][1] = y[i];
+                own[i][2] = qx[i];
+                own[i][3] = qy[i];
+                own[i][4] = p.sensing_radius[i];
+                own[i][5] = p.capture_radius[i];
+            }
+            write_obs_with_neighbours<N, 6>(x, y, own, p.num_neighbors, obs_env, D);
+        } else {
+            float own[N][4];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                own[i][0] = x[i];
+                own[i][1] = y[i];
+                own[i][2] = qx[i];
+                own[i][3] = qy[i];
+            }
+            write_obs_with_neighbours<N, 4>(x, y, own, p.num_neighbors, obs_env, D);
+        }
+        float r;
+        if (viol) {
+            r = p.violation_reward;
+            done = true;
+        } else {
+            r = 0.0f;
+            r = r + static_cast<float>(unseen0 - unseen1) * p.sense_reward;
+            r = r + static_cast<float>(left0 - left1) * p.capture_reward;
+            r = r + p.time_penalty;
+            if (steps > p.max_episode_steps || left1 == 0) {
+                done = true;
+                remaining = left1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) reward[i] = r;
+    } else if constexpr (SCN == RG_SCN_WAREHOUSE) {
+        uint8_t loaded[N];
+        float own[N][3];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            loaded[i] = a.st.loaded[eN + i];
+            own[i][0] = x[i];
+            own[i][1] = y[i];
+            own[i][2] = loaded[i] ? 1.0f : 0.0f;
+        }
+        write_obs_with_neighbours<N, 3>(x, y, own, p.num_neighbors, obs_env, D);
+        if (viol) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) reward[i] = p.violation_reward;
+            done = true;
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool green = (i % 2) == 0;
+                float r = 0.0f;
+                if (loaded[i]) {
+                    if (x[i] < -1.5f + p.goal_width && ((green && y[i] > 0.0f) || (!green && y[i] <= 0.0f))) {
+                        r = p.unload_reward;
+                        loaded[i] = 0;
+                    }
+                } else {
+                    if (x[i] > 1.5f - p.goal_width && ((!green && y[i] > 0.0f) || (green && y[i] <= 0.0f))) {
+                        r = p.load_reward;
+                        loaded[i] = 1;
+                    }
+                }
+                reward[i] = r;
+                a.st.loaded[eN + i] = loaded[i];
+            }
+            done = steps > p.max_episode_steps;
+        }
+    } else if constexpr (SCN == RG_SCN_SIMPLE) {
+        const float goal_x = a.st.prey_loc[static_cast<size_t>(e) * 2], goal_y = a.st.prey_loc[static_cast<size_t>(e) * 2 + 1];
+        float own[N][2];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            own[i][0] = x[i];
+            own[i][1] = y[i];
+        }
+        write_obs_with_neighbours<N, 2>(x, y, own, N - 1, obs_env, D);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            obs_env[i * D + 2 * N] = goal_x;
+            obs_env[i * D + 2 * N + 1] = goal_y;
+            if (viol) {
+                reward[i] = p.violation_reward;
+            } else {
+                const float dx = x[i] - goal_x, dy = y[i] - goal_y;
+                const float r = -(dx * dx + dy * dy);
+                reward[i] = r * p.reward_scaler;
+            }
+        }
+        done = viol ? true : steps > p.max_episode_steps;
+    } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+        static_assert(SCN != RG_SCN_ARCTIC_TRANSPORT || N == 4, "ArcticTransport has 4 agents");
+        const uint8_t *grid = a.st.grid + static_cast<size_t>(e) * 96;
+        const int gc = a.st.goal_col[e];
+        int row[N], col[N], reached[N], here[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            int r_ = -static_cast<int>((y[i] - 1.0f) / 0.25f), c_ = static_cast<int>((x[i] + 1.5f) / 0.25f);
+            row[i] = r_ < 0 ? 0 : r_ > 7 ? 7 : r_;
+            col[i] = c_ < 0 ? 0 : c_ > 11 ? 11 : c_;
+            here[i] = grid[row[i] * 12 + col[i]];
+            pix[i] = here[i];
+            reached[i] = a.st.reached_goal[eN + i] | (here[i] == 3 ? 1 : 0);
+        }
+        const float goalx = static_cast<float>(gc) * 0.25f - 1.5f, goaly = -1.0f * 0.25f + 0.75f;
+        float surround[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int left = col[i] > 0 ? col[i] - 1 : col[i], right = col[i] < 11 ? col[i] + 1 : col[i];
+            const int up = row[i] > 0 ? row[i] - 1 : row[i], down = row[i] < 7 ? row[i] + 1 : row[i];
+            surround[i][0] = static_cast<float>(grid[up * 12 + left]);
+            surround[i][1] = static_cast<float>(grid[row[i] * 12 + left]);
+            surround[i][2] = static_cast<float>(grid[down * 12 + left]);
+            surround[i][3] = static_cast<float>(grid[up * 12 + col[i]]);
+            surround[i][4] = static_cast<float>(grid[down * 12 + col[i]]);
+            surround[i][5] = static_cast<float>(grid[up * 12 + right]);
+            surround[i][6] = static_cast<float>(grid[row[i] * 12 + right]);
+            surround[i][7] = static_cast<float>(grid[down * 12 + right]);
+        }
+        sfor<0, N>([&](auto AA) {
+            constexpr int A = decltype(AA)::value;
+            constexpr int o0 = A == 0 ? 1 : A == 1 ? 0 : A == 2 ? 3 : 2, o1 = A < 2 ? 2 : 0, o2 = A < 2 ? 3 : 1;
+            float *o = obs_env + A * D;
+            o[0] = x[A];
+            o[1] = y[A];
+            o[2] = static_cast<float>(here[A]);
+            constexpr int oth[3] = {o0, o1, o2};
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                o[3 + 3 * m + 0] = x[oth[m]];
+                o[3 + 3 * m + 1] = y[oth[m]];
+                o[3 + 3 * m + 2] = static_cast<float>(here[oth[m]]);
+            }
+            o[12] = goalx;
+            o[13] = goaly;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o[14 + 8 * i + t] = surround[i][t];
+        });
+        float r;
+        if (viol) {
+            r = p.violation_reward;
+            done = true;
+        } else {
+            r = 0.0f;
+#pragma unroll
+            for (int jj = 2; jj < 4; ++jj) {
+                if (!reached[jj]) r = r + p.not_reached_penalty;
+                if (pix[jj] != 3) {
+                    const float dx = x[jj] - goalx, dy = y[jj] - goaly;
+                    r = r + p.dist_multiplier * (dx * dx + dy * dy);
+                }
+            }
+            done = steps > p.max_episode_steps;
+            if (!done) done = reached[2] && reached[3];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            reward[i] = r;
+            a.st.pixel_type[eN + i] = static_cast<uint8_t>(pix[i]);
+            a.st.reached_goal[eN + i] = static_cast<uint8_t>(reached[i]);
+        }
+    } else {  // MaterialTransport
+        int msg[4], load[N];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) msg[i] = i < N ? act[i < N ? i : 0] % 4 : a.st.messages[4 * e + i];
+        int zone0 = a.st.zone_load[2 * e], zone1 = a.st.zone_load[2 * e + 1];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            load[i] = a.st.load[eN + i];
+            float *o = obs_env + i * D;
+            o[0] = x[i];
+            o[1] = y[i];
+            o[2] = static_cast<float>(load[i]);
+            o[3] = static_cast<float>(zone0);
+            o[4] = static_cast<float>(zone1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[5 + t] = static_cast<float>(msg[t]);
+            if (p.capability_aware) {
+                o[9] = static_cast<float>(p.torque[i]);
+                o[10] = p.agent_step[i];
+            }
+        }
+        float r;
+        if (viol) {
+            r = p.violation_reward;
+            done = true;
+        } else {
+            r = p.time_penalty;
+            const float egw = p.end_goal_width, zr2 = p.zone1_radius * p.zone1_radius;
+            bool any_load = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {  // sequential over agents (MaterialTransport.py:161-189)
+                const int tq = p.torque[i];
+                if (load[i] > 0) {
+                    if (x[i] < -1.5f + egw) {
+                        r = r + static_cast<float>(load[i]) * p.unload_multiplier;
+                        load[i] = 0;
+                    }
+                } else {
+                    if (x[i] > 1.5f - egw) {
+                        if (zone1 > tq) {
+                            load[i] = tq;
+                            zone1 -= tq;
+                        } else {
+                            load[i] = zone1;
+                            zone1 = 0;
+                        }
+                        r = r + static_cast<float>(load[i]) * p.load_multiplier;
+                    } else if (x[i] * x[i] + y[i] * y[i] <= zr2) {
+                        if (zone0 > tq) {
+                            load[i] = tq;
+                            zone0 -= tq;
+                        } else {
+                            load[i] = zone0;
+                            zone0 = 0;
+                        }
+                        r = r + static_cast<float>(load[i]) * p.load_multiplier;
+                    }
+                }
+                any_load = any_load || (load[i] != 0);
+            }
+            done = steps > p.max_episode_steps;
+            if (!done) done = (zone0 == 0 && zone1 == 0 && !any_load);
+        }
+        if (done) {
+            remaining = zone0 + zone1;
+#pragma unroll
+            for (int i = 0; i < N; ++i) remaining += load[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            reward[i] = r;
+            a.st.load[eN + i] = load[i];
+        }
+        a.st.zone_load[2 * e] = zone0;
+        a.st.zone_load[2 * e + 1] = zone1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < N) a.st.messages[4 * e + i] = msg[i];
+    }
+
+    // ---- stores
+    {
+        float *X = a.st.poses + eN * 3;
+        float rsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            X[i] = x[i];
+            X[N + i] = y[i];
+            X[2 * N + i] = th[i];
+            a.st.carry_dist[eN + i] = last[i];
+            sv.io.reward[eN + i] = reward[i];
+            sv.io.dist_travelled[eN + i] = dist[i];
+            rsum = rsum + reward[i];
+        }
+        a.st.episode_steps[e] = steps;
+        if (stats) {  // misc.py:178-185
+            float ret = st_ret + (p.shared_reward ? reward[0] : rsum);
+            if (done) {
+                a.st.done_return_sum[e] = st_sum + ret;
+                a.st.done_count[e] = st_cnt + 1;
+                a.st.done_steps_sum[e] = st_steps + steps;
+                ret = 0.0f;
+            }
+            a.st.ep_return[e] = ret;
+        }
+        sv.io.done[e] = done ? 1 : 0;
+        sv.io.violation[e] = static_cast<uint8_t>(viol);
+        sv.io.remaining[e] = remaining;
+#ifdef RG_TPE_DIAG
+        max_sweeps = diag;  // diagnostic build: replayed-chunk mask << 16 | sweeps of QP 1 << 8 | sweeps of QP 2
+#endif
+        if (sv.io.qp_sweeps) sv.io.qp_sweeps[e] = max_sweeps;
+    }
+    return done;
+}
+
+// ------------------------------------------------------------------ the step kernel
+template <int SCN, int N, bool ROLLOUT>
+// (forcing the register budget of 3 waves per SIMD with amdgpu_waves_per_eu spills ~100 VGPRs at N = 5
+// and measured 1.7x slower; the natural allocation runs 2 waves per SIMD at N = 5, 6 and 3 at N <= 4)
+__global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
+    __shared__ Lds<WAVE> lds;
+    const int e = blockIdx.x * WAVE + threadIdx.x;
+    const int num_steps = ROLLOUT ? a.num_steps : 1;  // rg_rollout: no device-wide synchronisation between steps
+    for (int t = 0; t < num_steps; ++t) {
+        if (t) __syncthreads();  // the previous step's stores and resets are visible to the wave
+        bool done = false;
+        if (e < a.E) done = step_env<SCN, N>(a, step_view(a, t, N, a.p.obs_dim), e);
+        // fused auto-reset (scenario.reset(); ~1 env in 70 per step): the whole wave resets each finished
+        // env together, as one 64-lane group of the shared sampler
+        if (a.auto_reset) {
+            unsigned long long todo = __ballot(done);
+            if (todo) __syncthreads();  // the wave's state stores are complete before other lanes rewrite them
+            while (todo) {
+                const int i = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                reset_group<SCN, WAVE>(a, lds, blockIdx.x * WAVE + i, 0, threadIdx.x, true);
+            }
+        }
+    }
+}
+
+template <int SCN, bool ROLLOUT>
+static hipError_t launch_scn(const KernelArgs &a, hipStream_t stream) {
+    const int grid = (a.E + WAVE - 1) / WAVE;
+    switch (a.p.n_agents) {
+#define RG_CASE(NN)                                                                                   \
+    case NN:                                                                                          \
+        hipLaunchKernelGGL((step_kernel<SCN, NN, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);             \
+        break;
+        RG_CASE(2)
+        RG_CASE(3)
+        RG_CASE(4)
+        RG_CASE(5)
+        RG_CASE(6)
+        RG_CASE(7)
+        RG_CASE(8)
+#undef RG_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tpe
+
+template <bool ROLLOUT>
+static hipError_t launch_tpe(const KernelArgs &a, hipStream_t stream) {
+    switch (a.p.scenario) {
+        case RG_SCN_PREDATOR_CAPTURE_PREY:
+            return tpe::launch_scn<RG_SCN_PREDATOR_CAPTURE_PREY, ROLLOUT>(a, stream);
+        case RG_SCN_WAREHOUSE:
+            return tpe::launch_scn<RG_SCN_WAREHOUSE, ROLLOUT>(a, stream);
+        case RG_SCN_MATERIAL_TRANSPORT:
+            return tpe::launch_scn<RG_SCN_MATERIAL_TRANSPORT, ROLLOUT>(a, stream);
+        case RG_SCN_SIMPLE:
+            return tpe::launch_scn<RG_SCN_SIMPLE, ROLLOUT>(a, stream);
+        case RG_SCN_ARCTIC_TRANSPORT: {
+            const int grid = (a.E + WAVE - 1) / WAVE;
+            hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
+            return hipGetLastError();
+        }
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rg

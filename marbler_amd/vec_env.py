@@ -148,6 +148,38 @@ class VecRobotariumEnv(object):
         in self.obs / reward / done_u8 / dist_travelled / violation / remaining."""
         return self.lib.rg_step(self._h, actions_ptr, self._io_ref, 1 if self.auto_reset else 0, self.seed)
 
+    def rollout(self, actions, out=None):
+        """K env steps in one launch for an action sequence known up front (random-policy rollouts,
+        replayed logs, open-loop plans): actions int32 [K,E,N] on the device.  Returns a dict of
+        [K,...] tensors -- obs [K,E,N,D], reward [K,E,N], done [K,E] (uint8), dist_travelled [K,E,N],
+        violation [K,E], remaining [K,E] -- holding exactly what K calls of step() would have
+        returned (bit-identical; auto-reset as configured).  `out`: a dict from a previous call to
+        reuse its buffers.  The single-step buffers (self.obs, ...) are left untouched."""
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        K = int(actions.shape[0])
+        if tuple(actions.shape) != (K, self.E, self.N):
+            raise ValueError(f"actions must be [K,{self.E},{self.N}], got {tuple(actions.shape)}")
+        if out is None or out["obs"].shape[0] != K:
+            dev, f32 = self.device, torch.float32
+            out = {"obs": torch.empty(K, self.E, self.N, self.D, dtype=f32, device=dev),
+                   "reward": torch.empty(K, self.E, self.N, dtype=f32, device=dev),
+                   "done": torch.empty(K, self.E, dtype=torch.uint8, device=dev),
+                   "dist_travelled": torch.empty(K, self.E, self.N, dtype=f32, device=dev),
+                   "violation": torch.empty(K, self.E, dtype=torch.uint8, device=dev),
+                   "remaining": torch.empty(K, self.E, dtype=torch.int32, device=dev)}
+            if self.qp_sweeps is not None:
+                out["qp_sweeps"] = torch.empty(K, self.E, dtype=torch.int32, device=dev)
+            out["_io"] = _lib.RgStepIO(out["obs"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(),
+                                       out["dist_travelled"].data_ptr(), out["violation"].data_ptr(),
+                                       out["remaining"].data_ptr(),
+                                       out["qp_sweeps"].data_ptr() if "qp_sweeps" in out else None)
+        rc = self.lib.rg_rollout(self._h, actions.data_ptr(), K, C.byref(out["_io"]), 1 if self.auto_reset else 0,
+                                 self.seed)
+        if rc != 0:
+            _lib.check(rc, "rg_rollout")
+        return out
+
     def get_obs(self, out=None):
         """Observation of the current state without stepping (gymma's get_obs())."""
         out = self.obs if out is None else out

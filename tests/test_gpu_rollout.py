@@ -218,3 +218,40 @@ def test_large_batch_dispatch_matches_lane_group_kernel(monkeypatch):
     for k in s1:
         assert torch.equal(s1[k], s2[k]), k
     assert int(auto.done_count.sum()) > 0
+
+
+@pytest.mark.parametrize("scenario,ov,n_act,E", [
+    ("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 1000),
+    ("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 66000),   # thread-per-env: past its multi-step kernel's range
+    ("Warehouse", {"n_agents": 8}, 5, 300),
+    ("MaterialTransport", {}, 20, 129),
+    ("PredatorCapturePrey", {"predator": 6, "capture": 6, "n_agents": 12, "num_prey": 10, "start_dist": 0.25,
+                             "num_neighbors": 4}, 5, 40),
+    ("ArcticTransport", {}, 5, 200)])
+def test_rollout_entry_equals_repeated_steps(scenario, ov, n_act, E):
+    """rg_rollout (K steps in one launch, envs advancing independently) against K rg_step launches:
+    every per-step output and the final state, bit for bit, across auto-resets."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    K = 48
+    a = VecRobotariumEnv(scenario, E, overrides=ov, seed=21)
+    b = VecRobotariumEnv(scenario, E, overrides=ov, seed=21)
+    g = torch.Generator(device=a.device)
+    g.manual_seed(4)
+    a.reset()
+    b.reset()
+    for rep in range(3):   # three launches of K steps: the state carries over between launches
+        acts = torch.randint(0, n_act, (K, E, a.N), generator=g, device=a.device, dtype=torch.int32)
+        out = a.rollout(acts)
+        for k in range(K):
+            obs, rew, done, info = b.step(acts[k])
+            assert torch.equal(out["obs"][k].view(torch.int32), obs.view(torch.int32)), (rep, k)
+            assert torch.equal(out["reward"][k].view(torch.int32), rew.view(torch.int32)), (rep, k)
+            assert torch.equal(out["done"][k].bool(), done), (rep, k)
+            assert torch.equal(out["dist_travelled"][k].view(torch.int32), info["dist_travelled"].view(torch.int32))
+            assert torch.equal(out["violation"][k], info["violation"]) and torch.equal(out["remaining"][k], info["remaining"])
+    sa, sb = a.state_dict(), b.state_dict()
+    for key in sa:
+        assert torch.equal(sa[key], sb[key]), key
+    assert torch.equal(a.done_count, b.done_count) and int(a.done_count.sum()) > 0
+    assert torch.equal(a.done_return_sum.view(torch.int32), b.done_return_sum.view(torch.int32))

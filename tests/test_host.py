@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     from marbler_amd import _lib
     lib = _lib.load()
     names = _declared_functions()
-    assert {"rg_create", "rg_destroy", "rg_bind_state", "rg_reset", "rg_step", "rg_get_obs", "rg_abi_version",
+    assert {"rg_create", "rg_destroy", "rg_bind_state", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs", "rg_abi_version",
             "rg_last_error"} <= set(names)
     for n in names:
         assert hasattr(lib, n), n
@@ -41,6 +41,7 @@ def test_create_rejects_bad_parameters_without_touching_a_gpu():
     assert not lib.rg_create(ctypes.byref(p), 4, 0, 0, None)
     assert b"n_agents" in lib.rg_last_error()
     assert lib.rg_destroy(None) != 0 and lib.rg_step(None, None, None, 0, 0) != 0
+    assert lib.rg_rollout(None, None, 4, None, 0, 0) != 0
     # every check_params branch: each bad field is named in the error text
     base = lambda scn="PredatorCapturePrey": make_params(scn, load_config(scn))  # noqa: E731
     for scn, field, value, word in (("PredatorCapturePrey", "obs_dim", 18, b"multiple of 4"),

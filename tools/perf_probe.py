@@ -82,6 +82,28 @@ if __name__ == "__main__":
                 r["kernel"] = kern
                 # mean over waves of the per-64-env maximum of the step's sweep count (TPE divergence cost)
                 print(json.dumps(r), flush=True)
+    if args.set == "rollout":   # K steps per launch (rg_rollout) vs K launches (rg_step)
+        for kern in ("group", "tpe"):
+            os.environ["RG_STEP_KERNEL"] = kern
+            for E in ((4096, 32768) if kern == "group" else (32768, 524288)):
+                env = VecRobotariumEnv("PredatorCapturePrey", E, overrides=OV["PredatorCapturePrey"])
+                env.reset()
+                for K in (1, 4, 16, 64):
+                    if E * K > 524288 * 16:
+                        continue
+                    acts = torch.randint(0, 5, (K, E, 5), device=env.device, dtype=torch.int32)
+                    buf = env.rollout(acts)
+                    reps = max(4, 512 // K)
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(reps):
+                        env.rollout(acts, out=buf)
+                    b.record()
+                    torch.cuda.synchronize()
+                    us = a.elapsed_time(b) * 1e3 / (reps * K)
+                    print(json.dumps({"kernel": kern, "E": E, "K": K, "us_per_step": us,
+                                      "agent_steps_per_s": E * 5 / (us * 1e-6)}), flush=True)
     if args.set == "big":     # one saturated configuration (for rocprofv3 --pmc runs); RG_STEP_KERNEL picks the kernel
         out.append(probe("PredatorCapturePrey", 524288, steps=20, warm=10))
     for r in out:
