@@ -141,6 +141,7 @@ int rg_bind_state(rg_handle *h, const rg_state *st) {
         case RG_SCN_PREDATOR_CAPTURE_PREY:
             if (!st->prey_loc || !st->prey_sensed || !st->prey_captured)
                 return fail(-21, "PredatorCapturePrey needs prey_loc, prey_sensed, prey_captured");
+            if (reinterpret_cast<uintptr_t>(st->prey_loc) & 7u) return fail(-26, "prey_loc must be 8-byte aligned");
             break;
         case RG_SCN_WAREHOUSE:
             if (!st->loaded) return fail(-21, "Warehouse needs loaded");

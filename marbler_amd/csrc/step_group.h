@@ -238,10 +238,16 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
 // Diagnostic build only (-DRG_STAMPS, tools/stamp_probe.py): wave-cycle stamps of the step's
 // phases, written over io.qp_sweeps of the wave's first 8 envs.  No stamp executes in the
 // shipped library.
-#ifdef RG_STAMPS
+#if defined(RG_STAMPS) && defined(RG_STAMPS_EPI)  // slots 0..2 mark points inside the PCP epilogue instead
+#define RG_STAMP(i) \
+    if ((i) > 2) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
+#define RG_STAMP_E(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
+#elif defined(RG_STAMPS)
 #define RG_STAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
+#define RG_STAMP_E(i)
 #else
 #define RG_STAMP(i)
+#define RG_STAMP_E(i)
 #endif
 
 // ------------------------------------------------------------------ the step kernel
@@ -308,19 +314,20 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     int goal_col = 1, pix = 0, reached = 0;
     int load = 0, zone0 = 0, zone1 = 0;                      // MaterialTransport
     int msg[4] = {0, 0, 0, 0};
-    // PCP: the env's prey block is fetched into registers now (up to PRE floats per lane, i.e.
-    // P <= PRE*GW/2 prey) and put into LDS only when the epilogue needs it, so the load latency
-    // hides behind the sub-step loop; larger P take the direct copy below.
-    constexpr int PRE = 4;
-    float pre[PRE] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // PCP: up to 8 prey (the reference's configurations: 6) go straight into registers now -- every lane
+    // of the group loads the same 8 points, one request per group -- so the load latency hides behind
+    // the sub-step loop and the epilogue needs no LDS staging; larger prey counts are staged in LDS.
+    float2 prey_r[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) prey_r[t] = make_float2(0.0f, 0.0f);
     static_assert(SCN != RG_SCN_ARCTIC_TRANSPORT || GW == 4, "ArcticTransport is a 4-agent scenario");
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
         if (env_ok) {
-            if (2 * P <= PRE * GW) {
+            if (P <= 8) {
+                const float2 *src = reinterpret_cast<const float2 *>(a.st.prey_loc) + static_cast<size_t>(e) * P;
 #pragma unroll
-                for (int t = 0; t < PRE; ++t)
-                    if (ag + t * GW < 2 * P) pre[t] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + ag + t * GW];
+                for (int t = 0; t < 8; ++t) prey_r[t] = src[t < P ? t : P - 1];
             } else {
                 for (int i = ag; i < 2 * P; i += GW) lds.prey[g][i] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + i];
             }
@@ -561,12 +568,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
         const float sr2 = sr * sr, cr2 = cr * cr;
-        if (2 * P <= PRE * GW) {
-#pragma unroll
-            for (int t = 0; t < PRE; ++t)
-                if (ag + t * GW < 2 * P) lds.prey[g][ag + t * GW] = pre[t];
-        }
-        __syncthreads();  // LDS prey block visible (single-wave workgroup: waitcnt + s_barrier)
+        if (P > 8) __syncthreads();  // LDS prey block visible (single-wave workgroup: waitcnt + s_barrier)
         uint32_t nsen_lo = sen_lo, nsen_hi = sen_hi, ncap_lo = cap_lo, ncap_hi = cap_hi;
         // The prey block is scanned four at a time (LDS reads in flight together).  scan(lo, hi, f)
         // calls f(i, prey_x, prey_y, d2) for i in [lo, hi).
@@ -589,12 +591,8 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         if (P <= 8) {
             // common case (P = 6): the whole prey block in registers, one pass for tracking and
             // the nearest-prey search, no second trip to LDS
-            float2 pl[8];
+            const float2 (&pl)[8] = prey_r;
             float d2[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                pl[t] = *reinterpret_cast<const float2 *>(&lds.prey[g][2 * (t < P ? t : P - 1)]);
-            }
             uint32_t s_b = 0, c_b = 0;
             const bool acts = lane_ok & (act == 4);
 #pragma unroll
@@ -674,6 +672,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             if (P > 32) scan(32, P, nearest(ncap_hi, 32));
         }
         }
+        RG_STAMP_E(0);  // prey tracked, nearest prey found
         const int od = p.capability_aware ? 6 : 4;
         lds.own[lane][0] = x;
         lds.own[lane][1] = y;
@@ -692,6 +691,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             if (lane_ok) *reinterpret_cast<float4 *>(obs_row) = make_float4(x, y, qx, qy);
             write_neighbour_obs<GW, 4>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         }
+        RG_STAMP_E(1);  // observations written
         if constexpr (!OBS_ONLY) {  // a14 reward / termination (PredatorCapturePrey.py:155-176, 209-216)
             const int unseen0 = P - __builtin_popcount(sen_lo) - __builtin_popcount(sen_hi);
             const int left0 = P - __builtin_popcount(cap_lo) - __builtin_popcount(cap_hi);
