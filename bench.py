@@ -35,7 +35,7 @@ def measured_traffic():
         import csv
         kb = {}
         for r in csv.DictReader(open(path)):
-            if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and "rg::step_kernel<0, 8" in r["kernel"]:
+            if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and "rg::step_kernel<0, 8, false, 5, false>" in r["kernel"]:
                 kb[r["counter"]] = float(r["mean_per_launch"])
         if len(kb) == 2:
             return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, "profiles/r1_final_pmc_summary.csv"
@@ -256,7 +256,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "rg::step_kernel<PCP,GW=8> (lane group per env)" if E < 32768
+                         "kernel": "rg::step_kernel<PCP,GW=8,N=5> (lane group per env)" if E < 32768
                                    else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)",
                          "kernel_ms_avg": gpu_ms_total / K,   # HIP events around the timed region / K (back-to-back launches)
                          "kernel_ms_avg_event_pair_per_launch": kernel_ms,

@@ -30,7 +30,7 @@ if a.pmc:
             d = collections.defaultdict(list)
             for r in csv.DictReader(open(path)):
                 if "step_kernel" in r["Kernel_Name"]:
-                    d[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+                    d[(r["Kernel_Name"][:80], r["Counter_Name"])].append(float(r["Counter_Value"]))
             for (k, c), v in sorted(d.items()):
                 w.writerow([name, k, c, sum(v) / len(v), len(v)])
 if a.note:
