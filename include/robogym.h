@@ -178,6 +178,11 @@ int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t 
 int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg_step_io *io, int32_t auto_reset,
                uint64_t seed);
 
+/* The HIP stream later launches of this handle go to (rg_create's stream until changed).  Lets the
+ * caller record rg_step into a hipGraph: set the capturing stream, capture, replay -- the evaluation
+ * loop of misc.py:155-185 (policy forward, arg-max, env step) becomes one graph launch per step. */
+int rg_set_stream(rg_handle *h, void *hip_stream);
+
 /* The observation the scenario would build from the current state without stepping (the
  * reference returns zeros from reset(), PredatorCapturePrey.py:136; EPyMARL's gymma layer is
  * where get_obs() lives).  obs: [E][N][D]. */

@@ -69,7 +69,7 @@ class RgStepIO(C.Structure):
 
 
 EXPORTS = ("rg_abi_version", "rg_last_error", "rg_sizeof_params", "rg_sizeof_state", "rg_sizeof_step_io",
-           "rg_create", "rg_destroy", "rg_bind_state", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs")
+           "rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs")
 
 _lib = None
 
@@ -97,11 +97,12 @@ def load():
     lib.rg_create.argtypes = [C.POINTER(RgScenarioParams), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
     lib.rg_destroy.argtypes = [C.c_void_p]
     lib.rg_bind_state.argtypes = [C.c_void_p, C.POINTER(RgState)]
+    lib.rg_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.rg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.rg_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RgStepIO), C.c_int32, C.c_uint64]
     lib.rg_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(RgStepIO), C.c_int32, C.c_uint64]
     lib.rg_get_obs.argtypes = [C.c_void_p, C.c_void_p]
-    for f in (lib.rg_destroy, lib.rg_bind_state, lib.rg_reset, lib.rg_step, lib.rg_rollout, lib.rg_get_obs,
+    for f in (lib.rg_destroy, lib.rg_bind_state, lib.rg_set_stream, lib.rg_reset, lib.rg_step, lib.rg_rollout, lib.rg_get_obs,
               lib.rg_sizeof_params, lib.rg_sizeof_state, lib.rg_sizeof_step_io):
         f.restype = C.c_int
     if lib.rg_abi_version() != ABI_VERSION:

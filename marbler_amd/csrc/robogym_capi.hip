@@ -133,6 +133,12 @@ int rg_destroy(rg_handle *h) {
     return 0;
 }
 
+int rg_set_stream(rg_handle *h, void *hip_stream) {
+    if (!h) return fail(-1, "handle is NULL");
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    return 0;
+}
+
 int rg_bind_state(rg_handle *h, const rg_state *st) {
     if (!h || !st) return fail(-1, "handle or state is NULL");
     if (!st->poses || !st->carry_dist || !st->episode_steps || !st->reset_count)

@@ -74,27 +74,59 @@ def load_actor(model_file, model_config, n_agents, device="cuda:0"):
 
 
 @torch.no_grad()
-def run_eval(env, actor, steps, obs_agent_id=True):
+def run_eval(env, actor, steps, obs_agent_id=True, use_graph=False):
     """Greedy rollout of `actor` on a VecRobotariumEnv (auto_reset on) for `steps` env steps.
     Mirrors run_env's per-step body (misc.py:160-172): optional one-hot agent id appended to the
     observation, actor forward, arg-max, env.step; hidden states restart at zero with each episode.
-    Returns the statistics run_env prints, from the env's on-device accumulators."""
+    Returns the statistics run_env prints, from the env's on-device accumulators.
+
+    use_graph: record one iteration (a dozen small GEMM / elementwise launches plus the env step)
+    into a hipGraph on a side stream and replay it `steps` times -- the loop is launch-bound, the
+    replay is one launch per step.  Same arithmetic, same results."""
     E, N = env.E, env.N
     dev = env.device
     eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
-    obs = env.reset()
+    in_dim = env.D + (N if obs_agent_id else 0)
+    if in_dim != actor.input_dim:
+        raise ValueError(f"actor expects {actor.input_dim} inputs per agent, the env provides {in_dim}")
+    # loop-carried state lives in fixed buffers, updated in place (what a graph replay needs)
+    obs_in = env.reset().clone()
     hidden = actor.init_hidden(E)
     dist = torch.zeros(E, N, device=dev)
-    for _ in range(steps):
-        inp = torch.cat([obs, eye], dim=2) if obs_agent_id else obs
-        if inp.shape[2] != actor.input_dim:
-            raise ValueError(f"actor expects {actor.input_dim} inputs per agent, the env provides {inp.shape[2]}")
-        q, hidden = actor.forward(inp, hidden)
-        actions = q.argmax(dim=2).to(torch.int32)
+    actions = torch.zeros(E, N, dtype=torch.int32, device=dev)
+
+    def body():
+        inp = torch.cat([obs_in, eye], dim=2) if obs_agent_id else obs_in
+        q, h = actor.forward(inp, hidden)
+        actions.copy_(q.argmax(dim=2))
         obs, reward, done, info = env.step(actions)
-        dist += info["dist_travelled"]
-        hidden = torch.where(done[:, None, None], torch.zeros_like(hidden), hidden)
-        obs = torch.where(done[:, None, None], torch.zeros_like(obs), obs)   # the reference's reset() observation
+        dist.add_(info["dist_travelled"])
+        keep = (~done)[:, None, None]
+        hidden.copy_(torch.where(keep, h, 0.0))
+        obs_in.copy_(torch.where(keep, obs, 0.0))   # a finished env restarts from the reference's reset() observation (zeros)
+
+    if not use_graph:
+        for _ in range(steps):
+            body()
+    else:
+        side = torch.cuda.Stream(device=dev)
+        prev = env._stream
+        side.wait_stream(torch.cuda.current_stream(dev))
+        try:
+            env.set_stream(side)
+            with torch.cuda.stream(side):
+                n_warm = min(steps, 3)   # library handles and workspaces exist before the capture
+                for _ in range(n_warm):
+                    body()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    body()
+                for _ in range(steps - n_warm):
+                    graph.replay()
+            torch.cuda.current_stream(dev).wait_stream(side)
+        finally:
+            env.set_stream(prev)
+        torch.cuda.synchronize(dev)
     ret_sum, episodes, ep_steps = env.episode_stats()
     n = max(int(episodes), 1)
     return {"episodes": int(episodes), "mean_return": float(ret_sum) / n, "mean_steps": float(ep_steps) / n,

@@ -148,6 +148,13 @@ class VecRobotariumEnv(object):
         in self.obs / reward / done_u8 / dist_travelled / violation / remaining."""
         return self.lib.rg_step(self._h, actions_ptr, self._io_ref, 1 if self.auto_reset else 0, self.seed)
 
+    def set_stream(self, stream=None):
+        """Send later launches to `stream` (a torch.cuda.Stream; None = the current stream of the env's
+        device).  With a capturing stream the launches are recorded into the hipGraph being captured."""
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        _lib.check(self.lib.rg_set_stream(self._h, C.c_void_p(stream.cuda_stream)), "rg_set_stream")
+        self._stream = stream
+
     def rollout(self, actions, out=None):
         """K env steps in one launch for an action sequence known up front (random-policy rollouts,
         replayed logs, open-loop plans): actions int32 [K,E,N] on the device.  Returns a dict of

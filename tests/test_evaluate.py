@@ -44,3 +44,9 @@ def test_device_evaluation_loop():
     assert run_eval(env2, actor, steps=120) == out
     with pytest.raises(ValueError):
         run_eval(env2, actor, steps=1, obs_agent_id=False)
+    # one hipGraph launch per step instead of a dozen kernel launches: same statistics
+    env3 = VecRobotariumEnv("PredatorCapturePrey", 256, seed=5)
+    assert run_eval(env3, actor, steps=120, use_graph=True) == out
+    # the env is back on its own stream and still steps
+    obs, _, _, _ = env3.step(torch.zeros(256, env3.N, dtype=torch.int32, device=env3.device))
+    assert torch.isfinite(obs).all()
