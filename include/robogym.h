@@ -188,6 +188,32 @@ int rg_set_stream(rg_handle *h, void *hip_stream);
  * where get_obs() lives).  obs: [E][N][D]. */
 int rg_get_obs(rg_handle *h, float *obs);
 
+/* ---- policy inference for evaluation rollouts ------------------------
+ * The EPyMARL recurrent actor the reference evaluates with (utilities/rnn_agent.py:5-29 `RNNAgent`:
+ * fc1 -> ReLU -> GRUCell -> fc2; utilities/rnn_ns_agent.py:5-36 `RNNNSAgent`: one per agent), for all
+ * E x N agents in one launch on the matrix cores (f32-input MFMA: float32 products and sums).
+ * Weight arrays are torch's parameter layouts ([out][in] row-major), stacked over n_sets = 1 (shared)
+ * or N (one set per agent).  use_rnn = 0 (rnn_agent.py:13,27: Linear + ReLU instead of the GRU): that
+ * layer's weight / bias go in wih / bih, whh / bhh are ignored. */
+typedef struct {
+    const float *w1, *b1;   /* [S][H][I], [S][H] */
+    const float *wih, *bih; /* [S][3H][H], [S][3H]   (use_rnn = 0: [S][H][H], [S][H]) */
+    const float *whh, *bhh; /* [S][3H][H], [S][3H] */
+    const float *w2, *b2;   /* [S][A][H], [S][A] */
+    int32_t n_sets, input_dim, hidden_dim, n_actions, use_rnn;
+} rg_actor_weights;
+
+/* One actor step (misc.py:160-170: `actor(obs, hs)` then arg-max).  obs [E][N][D]; with
+ * append_agent_id the one-hot agent id is appended to each row (misc.py:162-164), D (+N) must equal
+ * input_dim.  hidden [E][N][H] is updated in place; restart [E] (or NULL) nonzero = a new episode in that
+ * env: its hidden state and its observation are taken as zero (what the reference's reset() returns,
+ * PredatorCapturePrey.py:136) -- pass the done flags of the previous rg_step.  q [E][N][A] (or NULL) receives the action values,
+ * actions [E][N] (or NULL) the greedy action.  hidden_dim 64 or 128, n_actions <= 32, input_dim <= 64. */
+int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
+                     int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden, float *q,
+                     int32_t *actions, void *hip_stream);
+const char *rg_actor_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

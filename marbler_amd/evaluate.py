@@ -64,6 +64,45 @@ class BatchedActor(object):
             h = torch.relu(self._lin(x, self.wr, self.br))
         return self._lin(h, self.w2, self.b2), h
 
+    # ------------------------------------------------------------------ fused HIP kernel (csrc/actor_mfma.hip)
+    def fused_supported(self):
+        return (self.w1.is_cuda and self.hidden_dim in (64, 128) and self.n_actions <= 32 and self.input_dim <= 64)
+
+    def _weights_struct(self):
+        from . import _lib
+        if getattr(self, "_ws", None) is None:
+            t = {k: getattr(self, k).contiguous() for k in ("w1", "b1", "w2", "b2")}
+            if self.use_rnn:
+                t.update({k: getattr(self, k).contiguous() for k in ("wih", "bih", "whh", "bhh")})
+            else:
+                t.update({"wih": self.wr.contiguous(), "bih": self.br.contiguous()})
+            ptr = lambda k: t[k].data_ptr() if k in t else None  # noqa: E731
+            self._ws_tensors = t   # keep the contiguous copies alive
+            self._ws = _lib.RgActorWeights(ptr("w1"), ptr("b1"), ptr("wih"), ptr("bih"), ptr("whh"), ptr("bhh"),
+                                           ptr("w2"), ptr("b2"), self.w1.shape[0], self.input_dim, self.hidden_dim,
+                                           self.n_actions, 1 if self.use_rnn else 0)
+        return self._ws
+
+    def forward_fused(self, obs, hidden, append_agent_id=True, restart=None, q_out=None, actions_out=None):
+        """One actor step for all E x N agents in one launch (rg_actor_forward, f32 MFMA).
+        obs [E,N,D] f32; hidden [E,N,H] f32 updated IN PLACE; restart [E] uint8 (nonzero = start that
+        env's hidden state from zero) or None.  Returns (q [E,N,A], actions [E,N] int32)."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        E, N, D = obs.shape
+        if q_out is None:
+            q_out = torch.empty(E, N, self.n_actions, device=obs.device)
+        if actions_out is None:
+            actions_out = torch.empty(E, N, dtype=torch.int32, device=obs.device)
+        stream = torch.cuda.current_stream(obs.device)
+        rc = lib.rg_actor_forward(C.byref(self._weights_struct()), E, N, obs.data_ptr(), D, 1 if append_agent_id else 0,
+                                  restart.data_ptr() if restart is not None else None, hidden.data_ptr(),
+                                  q_out.data_ptr(), actions_out.data_ptr(), C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise _lib.RobogymError("rg_actor_forward: " + lib.rg_actor_last_error().decode())
+        return q_out, actions_out
+
 
 def load_actor(model_file, model_config, n_agents, device="cuda:0"):
     """model_file: a `.th` state dict of the reference's model zoo; model_config: its sacred `.json`
@@ -74,7 +113,7 @@ def load_actor(model_file, model_config, n_agents, device="cuda:0"):
 
 
 @torch.no_grad()
-def run_eval(env, actor, steps, obs_agent_id=True, use_graph=False):
+def run_eval(env, actor, steps, obs_agent_id=True, use_graph=False, fused=None):
     """Greedy rollout of `actor` on a VecRobotariumEnv (auto_reset on) for `steps` env steps.
     Mirrors run_env's per-step body (misc.py:160-172): optional one-hot agent id appended to the
     observation, actor forward, arg-max, env.step; hidden states restart at zero with each episode.
@@ -82,7 +121,10 @@ def run_eval(env, actor, steps, obs_agent_id=True, use_graph=False):
 
     use_graph: record one iteration (a dozen small GEMM / elementwise launches plus the env step)
     into a hipGraph on a side stream and replay it `steps` times -- the loop is launch-bound, the
-    replay is one launch per step.  Same arithmetic, same results."""
+    replay is one launch per step.  Same arithmetic, same results.
+    fused (default: when the actor's shape allows): the whole policy step in one launch of the MFMA
+    kernel (csrc/actor_mfma.hip) -- an iteration is then three launches (actor, env step, distance
+    sum); float32 like the torch path, sums in a different order (action values agree to 1e-5)."""
     E, N = env.E, env.N
     dev = env.device
     eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
@@ -104,6 +146,19 @@ def run_eval(env, actor, steps, obs_agent_id=True, use_graph=False):
         keep = (~done)[:, None, None]
         hidden.copy_(torch.where(keep, h, 0.0))
         obs_in.copy_(torch.where(keep, obs, 0.0))   # a finished env restarts from the reference's reset() observation (zeros)
+
+    if fused is None:
+        fused = actor.fused_supported()
+    if fused:
+        q_buf = torch.empty(E, N, actor.n_actions, device=dev)
+
+        def body():  # noqa: F811 - the fused form of the loop body above
+            # env.obs / env.done_u8 are the previous step's outputs (zeros after reset()): a finished env is
+            # seen through a zero observation and a zero hidden state, inside the kernel
+            actor.forward_fused(env.obs, hidden, append_agent_id=obs_agent_id, restart=env.done_u8, q_out=q_buf,
+                                actions_out=actions)
+            env.step(actions)
+            dist.add_(env.dist_travelled)
 
     if not use_graph:
         for _ in range(steps):

@@ -27,10 +27,14 @@ def main():
     sys.modules.update({"robotarium_gym": pkg, "robotarium_gym.utilities": util})
     ra = _load("robotarium_gym.utilities.rnn_agent", os.path.join(REF, "rnn_agent.py"))
     rns = _load("robotarium_gym.utilities.rnn_ns_agent", os.path.join(REF, "rnn_ns_agent.py"))
-    for name, cls, use_rnn in (("actor_shared_gru", ra.RNNAgent, True), ("actor_shared_mlp", ra.RNNAgent, False),
-                               ("actor_ns_gru", rns.RNNNSAgent, True)):
+    # H = 16 keeps the fixtures small; the *_h64 ones have the hidden size of the model zoo's
+    # non-shared actors (the fused MFMA kernel of csrc/actor_mfma.hip takes 64 or 128)
+    for name, cls, use_rnn, H in (("actor_shared_gru", ra.RNNAgent, True, 16), ("actor_shared_mlp", ra.RNNAgent, False, 16),
+                                  ("actor_ns_gru", rns.RNNNSAgent, True, 16),
+                                  ("actor_shared_gru_h64", ra.RNNAgent, True, 64),
+                                  ("actor_ns_gru_h64", rns.RNNNSAgent, True, 64)):
         torch.manual_seed(7)
-        N, I, H, A, T = 4, 20, 16, 5, 6
+        N, I, A, T = 4, 20, 5, 6
         args = types.SimpleNamespace(hidden_dim=H, n_actions=A, use_rnn=use_rnn, n_agents=N)
         model = cls(I, args)
         x = torch.randn(T, N, I)

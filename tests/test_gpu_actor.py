@@ -1,0 +1,82 @@
+"""The fused actor kernel (csrc/actor_mfma.hip, f32 MFMA) against the torch float32 evaluation of the
+same weights (marbler_amd.evaluate.BatchedActor.forward, itself pinned to the reference's RNNAgent /
+RNNNSAgent modules by tests/test_evaluate.py): action values and hidden state within 1e-5, greedy
+actions equal wherever the top two action values are more than 1e-4 apart."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _random_actor(n_sets, I, H, A, use_rnn, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * 0.3  # noqa: E731
+    sd = {}
+    for i in range(n_sets):
+        pre = f"agents.{i}." if n_sets > 1 else ""
+        sd[pre + "fc1.weight"], sd[pre + "fc1.bias"] = r(H, I), r(H)
+        if use_rnn:
+            sd[pre + "rnn.weight_ih"], sd[pre + "rnn.weight_hh"] = r(3 * H, H), r(3 * H, H)
+            sd[pre + "rnn.bias_ih"], sd[pre + "rnn.bias_hh"] = r(3 * H), r(3 * H)
+        else:
+            sd[pre + "rnn.weight"], sd[pre + "rnn.bias"] = r(H, H), r(H)
+        sd[pre + "fc2.weight"], sd[pre + "fc2.bias"] = r(A, H), r(A)
+    return sd
+
+
+@pytest.mark.parametrize("shared,H,E,N,D,A,use_rnn,append", [
+    (True, 128, 300, 5, 16, 5, True, True),      # the PredatorCapturePrey model zoo shape (qmix.json)
+    (True, 64, 77, 4, 9, 20, True, True),        # MaterialTransport: 20 actions
+    (False, 64, 130, 5, 16, 5, True, False),     # rnn_ns: one network per agent, no agent id
+    (True, 128, 33, 8, 18, 5, False, True),      # use_rnn = False
+    (False, 128, 1, 3, 30, 5, True, False),      # a single env, ragged tile
+])
+def test_fused_actor_matches_torch(shared, H, E, N, D, A, use_rnn, append):
+    from marbler_amd.evaluate import BatchedActor
+    dev = "cuda:0"
+    I = D + (N if append else 0)
+    sd = _random_actor(1 if shared else N, I, H, A, use_rnn, seed=H + E)
+    actor = BatchedActor(sd, N, use_rnn=use_rnn, device=dev)
+    assert actor.fused_supported()
+    g = torch.Generator(device=dev).manual_seed(1)
+    hidden = (torch.rand(E, N, H, generator=g, device=dev) * 2 - 1)
+    eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
+    h_ref = hidden.clone()
+    for step in range(3):   # the hidden state feeds back
+        obs = torch.rand(E, N, D, generator=g, device=dev) * 3 - 1.5
+        restart = (torch.rand(E, generator=g, device=dev) < 0.2).to(torch.uint8)
+        fresh = restart.bool()[:, None, None]      # a new episode: zero observation, zero hidden state
+        obs_seen = torch.where(fresh, torch.zeros_like(obs), obs)
+        inp = torch.cat([obs_seen, eye], dim=2) if append else obs_seen
+        h_in = torch.where(restart.bool()[:, None, None], torch.zeros_like(h_ref), h_ref)
+        q_ref, h_ref = actor.forward(inp, h_in)
+        q, act = actor.forward_fused(obs, hidden, append_agent_id=append, restart=restart)
+        torch.cuda.synchronize()
+        assert float((q - q_ref).abs().max()) < 1e-5, step
+        assert float((hidden - h_ref).abs().max()) < 1e-5, step
+        top2 = q_ref.topk(2, dim=2).values
+        clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+        assert torch.equal(act[clear].long(), q_ref.argmax(dim=2)[clear])
+        assert bool(clear.float().mean() > 0.9)
+
+
+@pytest.mark.parametrize("name", ["actor_shared_gru_h64", "actor_ns_gru_h64"])
+def test_fused_actor_on_the_reference_vectors(name):
+    """Golden vectors from the reference's own RNNAgent / RNNNSAgent (tests/golden/make_actor_golden.py)."""
+    from marbler_amd.evaluate import BatchedActor
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    sd = {k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("sd_")}
+    T, N, I = g["inputs"].shape
+    actor = BatchedActor(sd, N, use_rnn=bool(g["use_rnn"]), device="cuda:0")
+    E = 3                                            # the same env three times: batching must not mix rows
+    hidden = actor.init_hidden(E)
+    for t in range(T):
+        x = torch.as_tensor(g["inputs"][t]).unsqueeze(0).expand(E, N, I).contiguous().cuda()   # carries the agent id already
+        q, _ = actor.forward_fused(x, hidden, append_agent_id=False)
+        for e in range(E):
+            assert np.abs(q[e].cpu().numpy() - g["q"][t]).max() < 1e-5
+            assert np.abs(hidden[e].cpu().numpy() - g["h"][t]).max() < 1e-5
