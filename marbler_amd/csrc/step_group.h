@@ -21,7 +21,7 @@
 // No MFMA: there is no dense contraction on this path.  At the benchmark size (4096 envs =
 // 512 wavefronts on 1024 SIMDs) the kernel is a latency-bound dependent chain per wavefront, so
 // the design goal is the shortest per-lane instruction chain with independent work interleaved
-// (sub-steps are processed in chunks of 4 for ILP), not bytes.
+// (sub-steps are processed in chunks of 5 for ILP), not bytes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
