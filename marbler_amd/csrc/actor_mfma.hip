@@ -4,8 +4,9 @@
 //
 // This is the one dense contraction on the path, so it runs on the matrix cores: f32-input MFMA
 // (v_mfma_f32_32x32x2_f32, exact f32 products and sums -- the parity bar against the reference's
-// float32 modules is 1e-5, which rules the 16x faster bf16 forms out).  One wavefront owns a tile
-// of 32 agent rows and carries it through the whole network:
+// float32 modules is 1e-5, which rules the 16x faster bf16 forms out).  One workgroup of H/32
+// wavefronts owns a tile of 32 agent rows and carries it through the whole network, wavefront w
+// computing the 32 hidden columns [32 w, 32 w + 32) of every layer:
 //     X [32 x I]  --fc1-->  Y1 [32 x H]  --GRU (6 gate tiles per 32 hidden columns)-->  h' [32 x H]  --fc2--> q [32 x A]
 // A operands (activations) are read from LDS as float4 = four k-steps; B operands (weights) stream
 // from L2 as float4 per lane (each weight matrix is read once per tile; all tiles share it in L2; fc1's
@@ -39,16 +40,19 @@ struct ActorArgs {
     int32_t E, N, D, append_agent_id, ip;  // ip = padded input width
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gate nonlinearities on the hardware exponential (v_exp_f32, ~1 ulp on 2^t): absolute error ~1e-7 on
+// outputs in [0, 1] / [-1, 1], far inside the 1e-5 parity bar, at a tenth of libm's instruction count
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
 template <int H>
-__global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
+__global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
     constexpr int HP = H + 4;  // LDS row pitch (floats): rows 16 B aligned, bank-staggered
+    constexpr int NTHREADS = 64 * (H / 32);
     __shared__ __attribute__((aligned(16))) float Xs[TM][MAX_IP + 4];
-    __shared__ __attribute__((aligned(16))) float W1s[32][MAX_IP + 4];  // fc1's weights, one 32-column block at a time
     __shared__ __attribute__((aligned(16))) float Y1[TM][HP];
     __shared__ __attribute__((aligned(16))) float Hs[TM][HP];
-    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6, half = lane >> 5, col = lane & 31;
     const int E = a.E, N = a.N, A = a.w.n_actions, I = a.w.input_dim, IP = a.ip;
     const bool shared = a.w.n_sets == 1;
     // tile -> weight set and rows
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
     const float *W2 = a.w.w2 + static_cast<size_t>(set) * A * H, *B2 = a.w.b2 + static_cast<size_t>(set) * A;
 
     // ---- stage the input rows (observation + optional one-hot agent id), the old hidden state and fc1's weights
-    for (int idx = lane; idx < TM * IP; idx += 64) {
+    for (int idx = tid; idx < TM * IP; idx += NTHREADS) {
         const int i = idx / IP, k = idx - i * IP;
         float v = 0.0f;
         if (row_ok(i)) {
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
         }
         Xs[i][k] = v;
     }
-    for (int idx = lane; idx < TM * (H / 4); idx += 64) {
+    for (int idx = tid; idx < TM * (H / 4); idx += NTHREADS) {
         const int i = idx / (H / 4), k4 = idx - i * (H / 4);
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (row_ok(i)) {
@@ -107,21 +111,22 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
     };
     auto crow = [&](int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; };  // tile row of accumulator register `reg`
 
-    // ---- fc1 + ReLU: Y1 = relu(X W1^T + b1)
-    for (int cb = 0; cb < H / 32; ++cb) {
+    // ---- fc1 + ReLU: Y1 = relu(X W1^T + b1); this wave's 32 columns.  The layer is small and its rows are
+    // ragged (I is not a multiple of 4): scalar operand loads, zero beyond I.
+    {
         const int n = cb * 32 + col;
-        if (cb) __syncthreads();  // the previous block's weights have been consumed
-        for (int idx = lane; idx < 32 * IP; idx += 64) {  // ragged rows (I is not a multiple of 4): staged zero-padded
-            const int nn = idx / IP, k = idx - nn * IP;
-            W1s[nn][k] = k < I ? W1[(cb * 32 + nn) * I + k] : 0.0f;
-        }
-        __syncthreads();
         floatx16 acc = zero16();
-        for (int kk = 0; kk < IP / 2; kk += 4) {
-            const float4 x = *reinterpret_cast<const float4 *>(&Xs[col][half * (IP / 2) + kk]);
-            const float4 w = *reinterpret_cast<const float4 *>(&W1s[col][half * (IP / 2) + kk]);
-            acc = mfma4(acc, x, w);
+        float w[MAX_IP / 2], xv[MAX_IP / 2];  // all operand loads in flight before the first product
+#pragma unroll
+        for (int kk = 0; kk < MAX_IP / 2; ++kk) {
+            const int k = half * (IP / 2) + kk;
+            const bool in = kk < IP / 2;
+            w[kk] = (in && k < I) ? W1[n * I + k] : 0.0f;
+            xv[kk] = in ? Xs[col][k] : 0.0f;
         }
+#pragma unroll
+        for (int kk = 0; kk < MAX_IP / 2; ++kk)
+            if (kk < IP / 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[kk], w[kk], acc, 0, 0, 0);
         const float b = B1[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) Y1[crow(r)][n] = fmaxf(acc[r] + b, 0.0f);
@@ -129,10 +134,9 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
     __syncthreads();
 
     // ---- recurrent layer
-    float hn[H / 32][16];  // the new hidden state in accumulator layout (the old one is still an operand)
-    if (a.w.use_rnn) {     // torch.nn.GRUCell: gates r, z, n in that order
-#pragma unroll
-        for (int cb = 0; cb < H / 32; ++cb) {
+    float hn[16];       // the new hidden state in accumulator layout (the old one is still an operand)
+    if (a.w.use_rnn) {  // torch.nn.GRUCell: gates r, z, n in that order
+        {
             const int j = cb * 32 + col;
             floatx16 gi[3], gh[3];
 #pragma unroll
@@ -140,35 +144,41 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
                 gi[g] = zero16();
                 gh[g] = zero16();
             }
-            // software-pipelined: the operands of k-step block kk+4 are in flight while block kk multiplies
-            // (one wave per SIMD here: nothing else hides the L2 latency of the weight stream)
-            struct Ops {
-                float4 x, h, wi[3], wh[3];
-            };
-            auto fetch = [&](int kk) {
-                Ops o;
-                const int k0 = half * (H / 2) + kk;
-                o.x = *reinterpret_cast<const float4 *>(&Y1[col][k0]);
-                o.h = *reinterpret_cast<const float4 *>(&Hs[col][k0]);
+            // The weight stream: lane (col, half) owns row g H + j of each gate matrix and, of that row, the
+            // k range of its half -- consumed in chunks of 32 floats = one 128-byte line per lane, eight
+            // float4 loads issued together, so a line is used up while it is hot (with 16 B per visit the
+            // 64 lines x 6 matrices a wave walks at once thrash L1 and every visit refetches its line from
+            // L2).  Groups (chunk, gate, matrix) are software-pipelined: the next group's line is in flight
+            // while this group's 32 MFMAs run.
+            constexpr int NCH = (H / 2) / 32;  // chunks per lane half
+            constexpr int NGROUPS = NCH * 6;
+            auto load_line = [&](int t, float4 (&wl)[8]) {
+                const int chunk = t / 6, g = (t % 6) >> 1, hh = t & 1;
+                const float *src = (hh ? Whh : Wih) + static_cast<size_t>(g * H + j) * H + half * (H / 2) + chunk * 32;
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const size_t wrow = static_cast<size_t>(g * H + j) * H + k0;
-                    o.wi[g] = *reinterpret_cast<const float4 *>(Wih + wrow);
-                    o.wh[g] = *reinterpret_cast<const float4 *>(Whh + wrow);
-                }
-                return o;
+                for (int q4 = 0; q4 < 8; ++q4) wl[q4] = *reinterpret_cast<const float4 *>(src + 4 * q4);
             };
-            Ops cur = fetch(0);
-#pragma unroll 2
-            for (int kk = 0; kk < H / 2; kk += 4) {
-                Ops nxt = cur;
-                if (kk + 4 < H / 2) nxt = fetch(kk + 4);
+            float4 wcur[8], wnext[8], xa[8], ha[8];
+            load_line(0, wcur);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    gi[g] = mfma4(gi[g], cur.x, cur.wi[g]);
-                    gh[g] = mfma4(gh[g], cur.h, cur.wh[g]);
+            for (int t = 0; t < NGROUPS; ++t) {
+                const int chunk = t / 6, g = (t % 6) >> 1, hh = t & 1;
+                if (t % 6 == 0) {  // this chunk's activations: A operands for all six products
+                    const int k0 = half * (H / 2) + chunk * 32;
+#pragma unroll
+                    for (int q4 = 0; q4 < 8; ++q4) {
+                        xa[q4] = *reinterpret_cast<const float4 *>(&Y1[col][k0 + 4 * q4]);
+                        ha[q4] = *reinterpret_cast<const float4 *>(&Hs[col][k0 + 4 * q4]);
+                    }
                 }
-                cur = nxt;
+                if (t + 1 < NGROUPS) load_line(t + 1, wnext);
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) {
+                    if (hh) gh[g] = mfma4(gh[g], ha[q4], wcur[q4]);
+                    else gi[g] = mfma4(gi[g], xa[q4], wcur[q4]);
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) wcur[q4] = wnext[q4];
             }
             const float bir = Bih[j], biz = Bih[H + j], bin = Bih[2 * H + j];
             const float bhr = Bhh[j], bhz = Bhh[H + j], bhn = Bhh[2 * H + j];
@@ -176,13 +186,12 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const float rg_ = sigmoidf_((gi[0][r] + bir) + (gh[0][r] + bhr));
                 const float zg = sigmoidf_((gi[1][r] + biz) + (gh[1][r] + bhz));
-                const float ng = tanhf((gi[2][r] + bin) + rg_ * (gh[2][r] + bhn));
-                hn[cb][r] = (1.0f - zg) * ng + zg * Hs[crow(r)][j];
+                const float ng = tanhf_((gi[2][r] + bin) + rg_ * (gh[2][r] + bhn));
+                hn[r] = (1.0f - zg) * ng + zg * Hs[crow(r)][j];
             }
         }
     } else {  // use_rnn = False: h = relu(Linear(x))  (rnn_agent.py:13,27); the weights sit in the wih / bih slots
-#pragma unroll
-        for (int cb = 0; cb < H / 32; ++cb) {
+        {
             const int j = cb * 32 + col;
             floatx16 acc = zero16();
             for (int kk = 0; kk < H / 2; kk += 4) {
@@ -192,24 +201,23 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
             }
             const float b = Bih[j];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hn[cb][r] = fmaxf(acc[r] + b, 0.0f);
+            for (int r = 0; r < 16; ++r) hn[r] = fmaxf(acc[r] + b, 0.0f);
         }
     }
     __syncthreads();  // every read of the old hidden state is done
-#pragma unroll
-    for (int cb = 0; cb < H / 32; ++cb) {
+    {
         const int j = cb * 32 + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = crow(r);
-            Hs[i][j] = hn[cb][r];
-            if (row_ok(i)) a.hidden[static_cast<size_t>(row_of(i)) * H + j] = hn[cb][r];
+            Hs[i][j] = hn[r];
+            if (row_ok(i)) a.hidden[static_cast<size_t>(row_of(i)) * H + j] = hn[r];
         }
     }
     __syncthreads();
 
-    // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one tile), then the greedy action per row
-    {
+    // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one tile, wavefront 0), then the greedy action per row
+    if (cb == 0) {
         floatx16 acc = zero16();
         const bool n_ok = col < A;
         for (int kk = 0; kk < H / 2; kk += 4) {
@@ -223,12 +231,12 @@ __global__ __launch_bounds__(64) void actor_kernel(const ActorArgs a) {
         for (int r = 0; r < 16; ++r) Y1[crow(r)][col] = acc[r] + b;  // Y1 is free again: the q tile, row-major
     }
     __syncthreads();
-    if (lane < TM && row_ok(lane)) {
-        const int r = row_of(lane);
-        float best = Y1[lane][0];
+    if (tid < TM && row_ok(tid)) {
+        const int r = row_of(tid);
+        float best = Y1[tid][0];
         int arg = 0;
         for (int n = 0; n < A; ++n) {
-            const float v = Y1[lane][n];
+            const float v = Y1[tid][n];
             if (a.q) a.q[static_cast<size_t>(r) * A + n] = v;
             if (v > best) {  // first maximum, like torch.argmax
                 best = v;
@@ -281,8 +289,8 @@ extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int
     const int tiles = w->n_sets == 1 ? (num_envs * n_agents + rg::TM - 1) / rg::TM
                                      : n_agents * ((num_envs + rg::TM - 1) / rg::TM);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (w->hidden_dim == 64) hipLaunchKernelGGL((rg::actor_kernel<64>), dim3(tiles), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((rg::actor_kernel<128>), dim3(tiles), dim3(64), 0, stream, a);
+    if (w->hidden_dim == 64) hipLaunchKernelGGL((rg::actor_kernel<64>), dim3(tiles), dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((rg::actor_kernel<128>), dim3(tiles), dim3(256), 0, stream, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(-30, hipGetErrorString(err));
     return 0;
