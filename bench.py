@@ -44,6 +44,54 @@ def measured_traffic():
     return None, None
 
 
+def _port_worker(seconds, seed):
+    """One NumPy-port env stepped for `seconds` on this process's core; prints the env-step count."""
+    import numpy as np
+    from oracle import np_port
+    from marbler_amd.params import load_config
+    cfg = load_config("PredatorCapturePrey", overrides=dict(PCP_OVERRIDES, seed=seed))
+    port = np_port.make_port("PredatorCapturePrey", cfg)
+    rng = np.random.RandomState(seed)
+    port.reset()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(25):
+            _, _, d, _ = port.step(list(rng.randint(0, 5, size=5)))
+            if d[0]:
+                port.reset()
+        n += 25
+    print(f"PORT_STEPS {n} {time.perf_counter() - t0:.3f}")
+
+
+def cpu_all_cores(seconds=8.0):
+    """the same port, one env per process, one process per host core (the shape of
+    EPyMARL's parallel runner).  CPU-only child processes; returns (agent-steps/s, processes)."""
+    import subprocess
+    n = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))   # one GPU's share of the host: 16 cores
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench._port_worker({seconds}, int(sys.argv[1]))"
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              text=True, env=env) for i in range(n)]
+    rate = 0.0
+    for pr in procs:
+        out, _ = pr.communicate(timeout=seconds * 6 + 120)
+        for line in out.splitlines():
+            if line.startswith("PORT_STEPS"):
+                _, steps, dt = line.split()
+                rate += int(steps) * 5 / float(dt)
+    return rate, n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The reference-shaped NumPy port (oracle/np_port.py: one env per object, Python loop over
     the 29 sub-iterations, float64) on ONE host core, same scenario config, random policy.
@@ -80,9 +128,14 @@ def cpu_baseline(seconds_budget=12.0):
     for k in range(40):
         env.step(acts[k])
     c_rate = 40 * E * 5 / (time.perf_counter() - t0)
+    all_rate, n_proc = cpu_all_cores()
     return {"value": py_rate, "unit": "agent-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} env-steps of 1 env x 5 agents, NumPy float64 port in the reference's shape "
                       f"(oracle/np_port.py), {dt:.1f} s on one core",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "all_cores": {"value": all_rate, "cores": n_proc, "kind": "port",
+                          "sample": f"{n_proc} processes x 1 env each (EPyMARL parallel-runner shape; one GPU's share of "
+                                    f"the host cores), 8 s"},
             "c_oracle_f64_1core": c_rate}
 
 
