@@ -201,6 +201,7 @@ typedef struct {
     const float *whh, *bhh; /* [S][3H][H], [S][3H] */
     const float *w2, *b2;   /* [S][A][H], [S][A] */
     int32_t n_sets, input_dim, hidden_dim, n_actions, use_rnn;
+    int32_t gru_packed;     /* wih / whh hold the streaming order written by rg_actor_pack_gru */
 } rg_actor_weights;
 
 /* One actor step (misc.py:160-170: `actor(obs, hs)` then arg-max).  obs [E][N][D]; with
@@ -212,6 +213,10 @@ typedef struct {
 int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
                      int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden, float *q,
                      int32_t *actions, void *hip_stream);
+/* Optional, once per actor: reorder a GRU weight array ([S][3H][H], torch layout) into the order the
+ * kernel streams it (1 KB per load instruction instead of 64 scattered 16-byte pieces).  dst: a device
+ * buffer of the same size; use it as wih / whh with gru_packed = 1. */
+int rg_actor_pack_gru(const float *src, int32_t n_sets, int32_t hidden_dim, float *dst, void *hip_stream);
 const char *rg_actor_last_error(void);
 
 #ifdef __cplusplus

@@ -72,12 +72,12 @@ class RgActorWeights(C.Structure):
     _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("wih", C.c_void_p), ("bih", C.c_void_p),
                 ("whh", C.c_void_p), ("bhh", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
                 ("n_sets", C.c_int32), ("input_dim", C.c_int32), ("hidden_dim", C.c_int32),
-                ("n_actions", C.c_int32), ("use_rnn", C.c_int32)]
+                ("n_actions", C.c_int32), ("use_rnn", C.c_int32), ("gru_packed", C.c_int32)]
 
 
 EXPORTS = ("rg_abi_version", "rg_last_error", "rg_sizeof_params", "rg_sizeof_state", "rg_sizeof_step_io",
            "rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs",
-           "rg_actor_forward", "rg_actor_last_error")
+           "rg_actor_forward", "rg_actor_pack_gru", "rg_actor_last_error")
 
 _lib = None
 
@@ -113,6 +113,8 @@ def load():
     lib.rg_actor_forward.argtypes = [C.POINTER(RgActorWeights), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rg_actor_forward.restype = C.c_int
+    lib.rg_actor_pack_gru.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rg_actor_pack_gru.restype = C.c_int
     lib.rg_actor_last_error.restype = C.c_char_p
     for f in (lib.rg_destroy, lib.rg_bind_state, lib.rg_set_stream, lib.rg_reset, lib.rg_step, lib.rg_rollout, lib.rg_get_obs,
               lib.rg_sizeof_params, lib.rg_sizeof_state, lib.rg_sizeof_step_io):

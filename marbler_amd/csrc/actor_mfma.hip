@@ -152,11 +152,19 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             // while this group's 32 MFMAs run.
             constexpr int NCH = (H / 2) / 32;  // chunks per lane half
             constexpr int NGROUPS = NCH * 6;
+            const bool packed = a.w.gru_packed != 0;
             auto load_line = [&](int t, float4 (&wl)[8]) {
                 const int chunk = t / 6, g = (t % 6) >> 1, hh = t & 1;
-                const float *src = (hh ? Whh : Wih) + static_cast<size_t>(g * H + j) * H + half * (H / 2) + chunk * 32;
+                const float *M = hh ? Whh : Wih;
+                if (packed) {  // rg_actor_pack_gru order: [cb][chunk][gate][q4][lane][4] -- one contiguous KB per load
+                    const float *src = M + (static_cast<size_t>((cb * NCH + chunk) * 3 + g) * 8) * 256 + lane * 4;
 #pragma unroll
-                for (int q4 = 0; q4 < 8; ++q4) wl[q4] = *reinterpret_cast<const float4 *>(src + 4 * q4);
+                    for (int q4 = 0; q4 < 8; ++q4) wl[q4] = *reinterpret_cast<const float4 *>(src + q4 * 256);
+                } else {
+                    const float *src = M + static_cast<size_t>(g * H + j) * H + half * (H / 2) + chunk * 32;
+#pragma unroll
+                    for (int q4 = 0; q4 < 8; ++q4) wl[q4] = *reinterpret_cast<const float4 *>(src + 4 * q4);
+                }
             };
             float4 wcur[8], wnext[8], xa[8], ha[8];
             load_line(0, wcur);
@@ -247,9 +255,39 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     }
 }
 
+// torch layout [S][3H][H] -> the kernel's streaming order [S][cb][chunk][gate][q4][lane = (half, col)][4]
+__global__ void pack_gru_kernel(const float *src, float *dst, int n_sets, int H) {
+    const int nch = (H / 2) / 32, ncb = H / 32;
+    const size_t total = static_cast<size_t>(n_sets) * 3 * H * H;
+    for (size_t o = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        size_t r = o;
+        const int f = r % 4; r /= 4;
+        const int lane = r % 64; r /= 64;
+        const int q4 = r % 8; r /= 8;
+        const int g = r % 3; r /= 3;
+        const int chunk = r % nch; r /= nch;
+        const int cb = r % ncb; r /= ncb;
+        const int s = static_cast<int>(r);
+        const int half = lane >> 5, col = lane & 31;
+        const int row = g * H + cb * 32 + col, k = half * (H / 2) + chunk * 32 + q4 * 4 + f;
+        dst[o] = src[(static_cast<size_t>(s) * 3 * H + row) * H + k];
+    }
+}
+
 }  // namespace rg
 
 static thread_local char g_actor_err[256] = "";
+
+extern "C" int rg_actor_pack_gru(const float *src, int32_t n_sets, int32_t hidden_dim, float *dst, void *hip_stream) {
+    if (!src || !dst || n_sets < 1 || (hidden_dim != 64 && hidden_dim != 128)) {
+        snprintf(g_actor_err, sizeof(g_actor_err), "rg_actor_pack_gru: NULL array, n_sets < 1 or hidden_dim not 64 / 128");
+        return -1;
+    }
+    hipLaunchKernelGGL(rg::pack_gru_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), src, dst, n_sets,
+                       hidden_dim);
+    return hipGetLastError() == hipSuccess ? 0 : -30;
+}
 
 extern "C" const char *rg_actor_last_error(void) { return g_actor_err; }
 

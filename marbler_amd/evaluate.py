@@ -18,11 +18,12 @@ import torch
 class BatchedActor(object):
     """RNNAgent / RNNNSAgent weights stacked as [A, ...] with A = 1 (shared) or N (one per agent)."""
 
-    def __init__(self, state_dict, n_agents, use_rnn=True, device="cpu"):
+    def __init__(self, state_dict, n_agents, use_rnn=True, device="cpu", pack_gru=True):
         keys = list(state_dict.keys())
         self.non_shared = keys[0].startswith("agents.")
         self.use_rnn = bool(use_rnn)
         self.n_agents = int(n_agents)
+        self.pack_gru = bool(pack_gru)   # fused kernel: reorder the GRU matrices once into its streaming order
 
         def stack(name):
             if self.non_shared:
@@ -69,18 +70,29 @@ class BatchedActor(object):
         return (self.w1.is_cuda and self.hidden_dim in (64, 128) and self.n_actions <= 32 and self.input_dim <= 64)
 
     def _weights_struct(self):
+        import ctypes as C
         from . import _lib
         if getattr(self, "_ws", None) is None:
             t = {k: getattr(self, k).contiguous() for k in ("w1", "b1", "w2", "b2")}
+            packed = 0
             if self.use_rnn:
                 t.update({k: getattr(self, k).contiguous() for k in ("wih", "bih", "whh", "bhh")})
-            else:
+            if self.use_rnn and self.pack_gru:
+                lib = _lib.load()   # reorder the two GRU matrices once into the kernel's streaming order
+                stream = C.c_void_p(torch.cuda.current_stream(self.w1.device).cuda_stream)
+                for k in ("wih", "whh"):
+                    dst = torch.empty_like(t[k])
+                    if lib.rg_actor_pack_gru(t[k].data_ptr(), self.w1.shape[0], self.hidden_dim, dst.data_ptr(), stream) != 0:
+                        raise _lib.RobogymError("rg_actor_pack_gru: " + lib.rg_actor_last_error().decode())
+                    t[k] = dst
+                packed = 1
+            if not self.use_rnn:
                 t.update({"wih": self.wr.contiguous(), "bih": self.br.contiguous()})
             ptr = lambda k: t[k].data_ptr() if k in t else None  # noqa: E731
             self._ws_tensors = t   # keep the contiguous copies alive
             self._ws = _lib.RgActorWeights(ptr("w1"), ptr("b1"), ptr("wih"), ptr("bih"), ptr("whh"), ptr("bhh"),
                                            ptr("w2"), ptr("b2"), self.w1.shape[0], self.input_dim, self.hidden_dim,
-                                           self.n_actions, 1 if self.use_rnn else 0)
+                                           self.n_actions, 1 if self.use_rnn else 0, packed)
         return self._ws
 
     def forward_fused(self, obs, hidden, append_agent_id=True, restart=None, q_out=None, actions_out=None):
