@@ -215,6 +215,12 @@ def main():
                     help="rehearsal only: every rank uses cuda:0 (a 1-GPU box); never for a measured run")
     args = ap.parse_args()
 
+    # The CPU baseline runs first, while this process has not touched the GPU: it starts child
+    # processes (one env each on the host cores), and nothing is exec'ed after HIP is initialised.
+    cpu_ref = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        cpu_ref = cpu_baseline()
+
     import torch
     import torch.distributed as dist
     from marbler_amd import VecRobotariumEnv, make_params, load_config
@@ -327,8 +333,8 @@ def main():
         if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey":
             out["rollout"] = rollout_leg(env, dev, n_act, 777)
             out["saturated"] = saturated_leg(dev, overrides)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if cpu_ref is not None:
+            out["cpu_baseline"] = cpu_ref
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
