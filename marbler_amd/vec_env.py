@@ -79,6 +79,7 @@ class VecRobotariumEnv(object):
         self.obs = torch.zeros(E, N, D, dtype=f32, device=dev)
         self.reward = torch.zeros(E, N, dtype=f32, device=dev)
         self.done_u8 = torch.zeros(E, dtype=u8, device=dev)
+        self.done = self.done_u8.view(torch.bool)   # the same bytes (the kernel writes 0 / 1): no conversion launch per step
         self.dist_travelled = torch.zeros(E, N, dtype=f32, device=dev)
         self.violation = torch.zeros(E, dtype=u8, device=dev)
         self.remaining = torch.full((E,), -1, dtype=i32, device=dev)
@@ -137,7 +138,7 @@ class VecRobotariumEnv(object):
         rc = self.lib.rg_step(self._h, actions.data_ptr(), self._io_ref, 1 if self.auto_reset else 0, self.seed)
         if rc != 0:
             _lib.check(rc, "rg_step")
-        return self.obs, self.reward, self.done_u8.bool(), self.info
+        return self.obs, self.reward, self.done, self.info
 
     @property
     def info(self):
