@@ -21,6 +21,8 @@ CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5
          ("Warehouse", {"n_agents": 8, "barrier_certificate": "default"}, 5, 150),
          ("PredatorCapturePrey", {"predator": 3, "capture": 2, "penalize_violations": False}, 5, 120),
          ("MaterialTransport", {"capability_aware": True, "qp_max_sweeps": 6}, 20, 80),
+         ("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "num_prey": 12}, 5, 150),   # > 8 prey: LDS / loop paths
+         ("PredatorCapturePrey", {"predator": 2, "capture": 2, "n_agents": 4, "num_prey": 33, "step_dist": 0.16}, 5, 100),  # > 32 prey: both flag words
          ("Simple", {}, 5, 130),
          ("Simple", {"n_agents": 6}, 5, 80),
          ("ArcticTransport", {}, 5, 200)]
