@@ -219,3 +219,19 @@ def params_from_bytes(b):
     p = RgScenarioParams()
     ctypes.memmove(ctypes.addressof(p), bytes(b), ctypes.sizeof(p))
     return p
+
+
+if __name__ == "__main__":   # python -m marbler_amd.params <Scenario> <out.bin> [key=value ...]: the YAML as an rg_scenario_params blob
+    import sys
+    if len(sys.argv) < 3:
+        raise SystemExit("usage: python -m marbler_amd.params <Scenario> <out.bin> [key=value ...]")
+    ov = {}
+    for kv in sys.argv[3:]:
+        k, v = kv.split("=", 1)
+        ov[k] = yaml.safe_load(v)
+    if sys.argv[1] == "PredatorCapturePrey" and ("predator" in ov or "capture" in ov):
+        cfg0 = load_config(sys.argv[1])
+        ov.setdefault("n_agents", int(ov.get("predator", cfg0["predator"])) + int(ov.get("capture", cfg0["capture"])))
+    with open(sys.argv[2], "wb") as fh:
+        fh.write(params_to_bytes(make_params(sys.argv[1], load_config(sys.argv[1], overrides=ov))))
+    print(f"wrote {sys.argv[2]} ({ctypes.sizeof(RgScenarioParams)} bytes)")
