@@ -315,7 +315,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "rg::step_kernel<PCP,GW=8,N=5> (lane group per env)" if E < 32768
+                         "kernel": "rg::step_kernel<PCP,GW=8,N=5> (lane group per env)" if E < 40960
                                    else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)",
                          "kernel_ms_avg": gpu_ms_total / K,   # HIP events around the timed region / K (back-to-back launches)
                          "kernel_ms_avg_event_pair_per_launch": kernel_ms,

@@ -194,12 +194,12 @@ def test_step_is_deterministic_and_shard_invariant():
 
 
 def test_large_batch_dispatch_matches_lane_group_kernel(monkeypatch):
-    """At 32768 envs the library picks the thread-per-env kernel on its own (robogym_capi.hip);
+    """At 49152 envs the library picks the thread-per-env kernel on its own (robogym_capi.hip);
     every output and the whole state must equal the lane-group kernel's, bit for bit, over steps
     that include auto-resets."""
     import torch
     from marbler_amd import VecRobotariumEnv
-    E, ov = 32768, {"predator": 3, "capture": 2, "n_agents": 5}
+    E, ov = 49152, {"predator": 3, "capture": 2, "n_agents": 5}
     monkeypatch.delenv("RG_STEP_KERNEL", raising=False)
     auto = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov, seed=5)
     monkeypatch.setenv("RG_STEP_KERNEL", "group")
