@@ -41,6 +41,54 @@ static int32_t tpe_min_envs(const rg_scenario_params &p) {
     }
 }
 
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+static int check_params(const rg_scenario_params *p) {
+    if (!p) return fail(-1, "params is NULL");
+    if (p->scenario < RG_SCN_PREDATOR_CAPTURE_PREY || p->scenario > RG_SCN_ARCTIC_TRANSPORT)
+        return fail(-2, "unknown scenario id");
+    if (p->n_agents < 1 || p->n_agents > RG_MAX_AGENTS) return fail(-3, "n_agents must be in 1..16");
+    if (p->update_frequency < 1 || p->controller_period < 1) return fail(-4, "update_frequency / controller_period < 1");
+    if (p->obs_dim < 1) return fail(-5, "obs_dim < 1");
+    if (p->qp_max_sweeps < 1 || !(p->qp_rtol >= 0.0f)) return fail(-5, "qp_max_sweeps < 1 or qp_rtol < 0");
+    if (p->collision_variant != RG_COLLISION_CENTER && p->collision_variant != RG_COLLISION_OFFSET)
+        return fail(-6, "unknown collision_variant");
+    const rg_grid &g = p->agent_grid;
+    // rps generate_initial_conditions asserts cells > N (Appendix A.7)
+    if (g.nx < 1 || g.ny < 1 || g.nx * g.ny <= p->n_agents || g.nx * g.ny > 64)
+        return fail(-7, "agent reset grid must have n_agents < nx*ny <= 64");
+    if (p->scenario == RG_SCN_PREDATOR_CAPTURE_PREY) {
+        if (p->num_prey < 1 || p->num_prey > RG_MAX_PREY) return fail(-8, "num_prey must be in 1..64");
+        const rg_grid &q = p->prey_grid;
+        if (q.nx < 1 || q.ny < 1 || q.nx * q.ny <= p->num_prey || q.nx * q.ny > 64)
+            return fail(-9, "prey reset grid must have num_prey < nx*ny <= 64");
+        const int od = p->capability_aware ? 6 : 4;
+        const int nb = p->num_neighbors >= p->n_agents - 1 ? p->n_agents - 1 : p->num_neighbors;
+        if (p->obs_dim < od * (nb + 1)) return fail(-10, "obs_dim too small for PredatorCapturePrey");
+        // the 4-float observation blocks are written with 16-byte stores
+        if (od == 4 && (p->obs_dim & 3)) return fail(-10, "obs_dim must be a multiple of 4 for PredatorCapturePrey without capability_aware");
+    } else if (p->scenario == RG_SCN_WAREHOUSE) {
+        const int nb = p->num_neighbors >= p->n_agents - 1 ? p->n_agents - 1 : p->num_neighbors;
+        if (p->obs_dim < 3 * (nb + 1)) return fail(-10, "obs_dim too small for Warehouse");
+    } else if (p->scenario == RG_SCN_SIMPLE) {
+        if (p->num_prey != 1) return fail(-8, "Simple has one goal (num_prey = 1)");
+        const rg_grid &q = p->prey_grid;
+        if (q.nx < 1 || q.ny < 1 || q.nx * q.ny <= 1 || q.nx * q.ny > 64) return fail(-9, "goal reset grid must have 1 < nx*ny <= 64");
+        if (p->obs_dim < 2 * (p->n_agents + 1)) return fail(-10, "obs_dim too small for Simple");
+    } else if (p->scenario == RG_SCN_ARCTIC_TRANSPORT) {
+        if (p->n_agents != 4) return fail(-3, "ArcticTransport has exactly 4 agents");
+        if (p->obs_dim < 30) return fail(-10, "obs_dim too small for ArcticTransport");
+    } else {
+        if (p->obs_dim < (p->capability_aware ? 11 : 9)) return fail(-10, "obs_dim too small for MaterialTransport");
+    }
+    return 0;
+}
+
 extern "C" {
 
 int rg_abi_version(void) { return RG_ABI_VERSION; }
