@@ -468,13 +468,14 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     c = cn;
                     s = sn;
                 });
-                int dmin = 0x7FFFFFFF;
+                int dmin_u[C];  // per sub-step: the replay runs the exact pair test only where the pre-test fired
                 static_for<0, C>([&](auto UU) {
                     constexpr int u = decltype(UU)::value;
+                    dmin_u[u] = 0x7FFFFFFF;
                     auto test = [&](int partner_q) {
                         const half2v dq = __builtin_bit_cast(half2v, q[u]) - __builtin_bit_cast(half2v, partner_q);
                         const int d2 = dot2_bits(dq);
-                        dmin = d2 < dmin ? d2 : dmin;
+                        dmin_u[u] = d2 < dmin_u[u] ? d2 : dmin_u[u];
                     };
                     if constexpr (GW == 8 && NT >= 5 && NT <= 7) {
                         // the pre-test may visit the pairs in any order: the three quad rounds cover the
@@ -489,14 +490,22 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                         static_for<1, GW>([&](auto KK) { test(xor_lane_i<decltype(KK)::value>(q[u])); });
                     }
                 });
+                int dmin = dmin_u[0];
+                static_for<1, C>([&](auto UU) { dmin = dmin_u[decltype(UU)::value] < dmin ? dmin_u[decltype(UU)::value] : dmin; });
                 if (penalize && __any((dmin <= thr_pre) | bnd_any)) {
-                    // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
+                    // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94): the
+                    // boundary test on every sub-step (per lane, cheap), the pair rounds only on the sub-steps
+                    // whose own pre-test fired somewhere in the wave (robots cross the 3 mm pre-test band
+                    // within a sub-step or two: most sub-steps of a flagged chunk need no pair rounds)
                     float rx = x0, ry = y0, rc = c0, rs = s0;
-                    for (int u = 0; u < C; ++u) {
+                    static_for<0, C>([&](auto UU) {
+                        constexpr int u = decltype(UU)::value;
                         const bool bnd = lane_ok & !dead & ((rx < k.xmin) | (rx > k.xmax) | (ry < k.ymin) | (ry > k.ymax));
                         const float fx = __builtin_fmaf(k.coll_off, rc, rx), fy = __builtin_fmaf(k.coll_off, rs, ry);
                         bool col = false;
-                        if constexpr (GW == 8 && NT >= 5 && NT <= 7) {  // same pair cover as the pre-test: 3 + (N-4) rounds
+                        if (!__any(dmin_u[u] <= thr_pre)) {
+                            // no pair of this sub-step is within the pre-test band: no collision possible
+                        } else if constexpr (GW == 8 && NT >= 5 && NT <= 7) {  // same pair cover as the pre-test: 3 + (N-4) rounds
                             static_for<1, 4>([&](auto KK) {
                                 constexpr int K = decltype(KK)::value;
                                 const float dx = fx - xor_lane<K>(fx), dy = fy - xor_lane<K>(fy);
@@ -530,7 +539,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                         const float sn = __builtin_fmaf(rs, cd, rc * sd);
                         rc = cn;
                         rs = sn;
-                    }
+                    });
                 }
             };
             int j = 0;
