@@ -226,9 +226,7 @@ def main():
     from marbler_amd import VecRobotariumEnv, make_params, load_config
     from marbler_amd import dist as rgdist
 
-    rank, world, local = rgdist.init_from_env(backend=args.dist_backend)
-    if args.share_gpu:
-        local = 0
+    rank, world, local = rgdist.init_from_env(backend=args.dist_backend, device_index=0 if args.share_gpu else None)
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)

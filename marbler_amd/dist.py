@@ -13,12 +13,15 @@ import torch.distributed as dist
 from .params import params_from_bytes, params_to_bytes
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, device_index=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
-    Returns (rank, world_size, local_rank).  world_size 1: no process group is created."""
+    Returns (rank, world_size, local_rank).  world_size 1: no process group is created.
+    device_index: the GPU of this rank if it is not LOCAL_RANK (rehearsals on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if device_index is not None:
+        local = int(device_index)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
