@@ -4,7 +4,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # (this file lives in tests/: only tests may use the oracle)
 import test_gpu_rollout as T
 from oracle import c_oracle
 c_oracle.build_library()
