@@ -268,8 +268,9 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     const int ag = lane & (GW - 1);
     const int g = lane / GW;
     const int gbase = lane & ~(GW - 1);
-    const int e = blockIdx.x * EPW + g;
-    const bool env_ok = e < a.E;
+    const int epw = a.half_waves ? EPW / 2 : EPW;
+    const int e = blockIdx.x * epw + g;
+    const bool env_ok = (g < epw) & (e < a.E);
     const bool lane_ok = env_ok && ag < N;
     const size_t eN = static_cast<size_t>(e) * N;
 
@@ -1035,9 +1036,20 @@ namespace rg {
 inline int group_width(int N) { return N <= 4 ? 4 : N <= 8 ? 8 : 16; }
 
 template <int SCN, bool OBS_ONLY, bool ROLLOUT>
-static hipError_t launch_step_scn(const KernelArgs &a, hipStream_t stream) {
-    const int gw = group_width(a.p.n_agents);
-    const int grid = (a.E + WAVE / gw - 1) / (WAVE / gw);
+static hipError_t launch_step_scn(const KernelArgs &a_in, hipStream_t stream) {
+    const int gw = group_width(a_in.p.n_agents);
+    // A batch that fills at most half the chip's 1024 SIMDs with full wavefronts runs with half-filled
+    // ones instead (twice as many waves, each carrying half as many envs): a wave's time is the maximum
+    // over its envs (QP sweeps, replays, resets), and the idle SIMDs are free.
+    KernelArgs a = a_in;
+    int epw = WAVE / gw;
+#ifndef RG_STAMPS
+    if (epw >= 2 && (a.E + epw - 1) / epw <= 512) {
+        a.half_waves = 1;
+        epw /= 2;
+    }
+#endif
+    const int grid = (a.E + epw - 1) / epw;
     if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, OBS_ONLY, 0, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
     else if (gw == 16) hipLaunchKernelGGL((step_kernel<SCN, 16, OBS_ONLY, 0, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
     else if constexpr (OBS_ONLY) hipLaunchKernelGGL((step_kernel<SCN, 8, true, 0, false>), dim3(grid), dim3(WAVE), 0, stream, a);
