@@ -70,7 +70,7 @@ struct KernelArgs {
     const int32_t *actions;
     const uint8_t *reset_mask;
     int32_t E;
-    int32_t half_waves; // lane-group kernel: only the lower half of each wave's env slots is used (small batches, see launch_step_scn)
+    int32_t envs_per_wave; // lane-group kernel: env slots used per wavefront (0 = all 64/GW; fewer for small batches, see launch_step_scn)
     int32_t num_steps;  // env steps per launch (rg_step: 1); io and actions carry a leading dimension of this size
     int32_t auto_reset;
     int64_t env_offset;

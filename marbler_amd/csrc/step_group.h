@@ -268,7 +268,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     const int ag = lane & (GW - 1);
     const int g = lane / GW;
     const int gbase = lane & ~(GW - 1);
-    const int epw = a.half_waves ? EPW / 2 : EPW;
+    const int epw = a.envs_per_wave > 0 ? a.envs_per_wave : EPW;
     const int e = blockIdx.x * epw + g;
     const bool env_ok = (g < epw) & (e < a.E);
     const bool lane_ok = env_ok && ag < N;
@@ -1038,16 +1038,14 @@ inline int group_width(int N) { return N <= 4 ? 4 : N <= 8 ? 8 : 16; }
 template <int SCN, bool OBS_ONLY, bool ROLLOUT>
 static hipError_t launch_step_scn(const KernelArgs &a_in, hipStream_t stream) {
     const int gw = group_width(a_in.p.n_agents);
-    // A batch that fills at most half the chip's 1024 SIMDs with full wavefronts runs with half-filled
-    // ones instead (twice as many waves, each carrying half as many envs): a wave's time is the maximum
-    // over its envs (QP sweeps, replays, resets), and the idle SIMDs are free.
+    // A batch that leaves SIMDs idle with full wavefronts runs with partly filled ones instead (more
+    // waves, each carrying fewer envs, as long as there is at most one wave per SIMD: 1024): a wave's
+    // time is the maximum over its envs (QP sweeps, replays, resets), and the idle SIMDs are free.
     KernelArgs a = a_in;
     int epw = WAVE / gw;
 #ifndef RG_STAMPS
-    if (epw >= 2 && (a.E + epw - 1) / epw <= 512) {
-        a.half_waves = 1;
-        epw /= 2;
-    }
+    while (epw >= 2 && (a.E + epw / 2 - 1) / (epw / 2) <= 1024) epw /= 2;
+    a.envs_per_wave = epw;
 #endif
     const int grid = (a.E + epw - 1) / epw;
     if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, OBS_ONLY, 0, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
