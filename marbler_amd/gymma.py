@@ -50,6 +50,9 @@ class GymmaVecEnv(object):
         self._elapsed = torch.zeros(self.E, dtype=torch.int32, device=self.env.device)
         self._avail = torch.ones(self.E, self.n_agents, self.n_actions, dtype=torch.int32, device=self.env.device)
         self._obs = self.env.obs
+        # gym's TimeLimit can only fire if it is not longer than the scenario's own horizon
+        # (episodes end at step max_episode_steps + 1 at the latest): otherwise nothing to do per step
+        self._can_truncate = self.episode_limit <= int(self.env.params.max_episode_steps) + 1
 
     # -- gymma surface, batched
     def reset(self):
@@ -64,13 +67,13 @@ class GymmaVecEnv(object):
         obs, reward, done, info = self.env.step(actions)
         self._elapsed += 1
         truncated = (self._elapsed >= self.episode_limit) & ~done          # gym TimeLimit
-        if bool(truncated.any()):
-            self.env.reset(truncated)
         ended = done | truncated
         # the kernel has already reset `done` envs; gymma users see zeros after a reset (the reference's reset obs)
         self._obs = torch.where(ended[:, None, None], torch.zeros_like(obs), obs)
-        self._terminal_obs = obs
-        self._elapsed[ended] = 0
+        self._terminal_obs = obs.clone() if self._can_truncate else obs
+        if self._can_truncate:
+            self.env.reset(truncated)   # masked launch, no host round trip (waves without a flagged env exit at once)
+        self._elapsed.masked_fill_(ended, 0)
         out = dict(info)
         out["TimeLimit.truncated"] = truncated
         return reward.sum(dim=1), ended, out

@@ -124,7 +124,7 @@ class VecRobotariumEnv(object):
             if mask is None:
                 self.obs.zero_()
             else:
-                self.obs[mask.bool()] = 0
+                self.obs.masked_fill_(mask.bool()[:, None, None], 0.0)   # no host round trip (boolean indexing would sync)
             return self.obs
         return self.get_obs()
 
