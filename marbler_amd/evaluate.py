@@ -198,3 +198,36 @@ def run_eval(env, actor, steps, obs_agent_id=True, use_graph=False, fused=None):
     n = max(int(episodes), 1)
     return {"episodes": int(episodes), "mean_return": float(ret_sum) / n, "mean_steps": float(ep_steps) / n,
             "mean_dist_per_step": float(dist.sum()) / (steps * E * N)}
+
+
+def main(argv=None):
+    """`python -m marbler_amd.evaluate --scenario PredatorCapturePrey --model-file qmix.th --model-config qmix.json`
+    -- the batched counterpart of `python -m robotarium_gym.main --scenario X` (main.py / misc.py:93-221):
+    loads a model of the reference's zoo, rolls it out greedily on --envs envs for --steps steps, prints
+    the statistics run_env prints (mean return, mean episode length) as one JSON line."""
+    import argparse
+    from .params import load_config
+    from .vec_env import VecRobotariumEnv
+    ap = argparse.ArgumentParser(prog="python -m marbler_amd.evaluate")
+    ap.add_argument("--scenario", required=True)
+    ap.add_argument("--model-file", required=True, help="a .th state dict of the model zoo")
+    ap.add_argument("--model-config", required=True, help="its sacred .json config")
+    ap.add_argument("--config", default=None, help="scenario YAML (default: this package's copy of the reference's)")
+    ap.add_argument("--envs", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--torch-actor", action="store_true", help="evaluate the policy with torch ops instead of the fused kernel")
+    args = ap.parse_args(argv)
+    cfg = load_config(args.scenario, config_path=args.config)
+    env = VecRobotariumEnv(args.scenario, args.envs, overrides=cfg, device=args.device, seed=args.seed)
+    actor, mcfg = load_actor(args.model_file, args.model_config, env.N, device=args.device)
+    out = run_eval(env, actor, args.steps, obs_agent_id=bool(mcfg.get("obs_agent_id", True)),
+                   fused=False if args.torch_actor else None)
+    out.update({"scenario": args.scenario, "envs": args.envs, "steps": args.steps})
+    print(json.dumps(out))
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -50,3 +50,23 @@ def test_device_evaluation_loop():
     # the env is back on its own stream and still steps
     obs, _, _, _ = env3.step(torch.zeros(256, env3.N, dtype=torch.int32, device=env3.device))
     assert torch.isfinite(obs).all()
+
+
+@pytest.mark.gpu
+def test_evaluate_cli_on_a_model_zoo_shaped_checkpoint(tmp_path):
+    """`python -m marbler_amd.evaluate` (the batched `python -m robotarium_gym.main`): a `.th` state dict and a
+    sacred `.json` in the reference's formats (random weights of the zoo's shapes; the zoo itself stays in
+    the reference), default PredatorCapturePrey config (4 agents, 16 + 4 inputs)."""
+    import json
+    from marbler_amd import evaluate
+    from test_gpu_actor import _random_actor
+    sd = _random_actor(1, 20, 64, 5, True, seed=11)
+    torch.save(sd, tmp_path / "qmix.th")
+    (tmp_path / "qmix.json").write_text(json.dumps({"use_rnn": True, "obs_agent_id": True, "hidden_dim": 64, "agent": "rnn"}))
+    argv = ["--scenario", "PredatorCapturePrey", "--model-file", str(tmp_path / "qmix.th"),
+            "--model-config", str(tmp_path / "qmix.json"), "--envs", "96", "--steps", "100"]
+    fused = evaluate.main(argv)
+    eager = evaluate.main(argv + ["--torch-actor"])
+    assert fused["episodes"] >= 96 and 0 < fused["mean_steps"] <= 81 and np.isfinite(fused["mean_return"])
+    # same policy, float32 both ways: the two evaluations may part ways only through 1e-6-level ties in arg-max
+    assert abs(fused["mean_return"] - eager["mean_return"]) < 1.0 and abs(fused["episodes"] - eager["episodes"]) <= 10
