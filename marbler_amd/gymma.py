@@ -201,3 +201,63 @@ class GymmaEnv(object):
 
     def get_stats(self):
         return {}
+
+
+class BatchedRunner(object):
+    """The data-collection half of EPyMARL's `parallel` runner (`runners/parallel_runner.py::run`, external to
+    the reference; its consumer contract is the gymma one above) for E envs at once: a recurrent actor picks
+    epsilon-greedy actions from the padded observations (+ agent id), the envs step, and the transition
+    tensors EPyMARL stores per time step -- obs, state, avail_actions, actions, reward, terminated -- come
+    back time-major with a leading [T] axis, all on the device.  Envs that finish restart inside the
+    rollout (the hidden state of their agents restarts at zero), so there is no padding to an episode
+    limit: `terminated[t, e]` marks episode ends, `episode_start[t, e]` the first step of an episode."""
+
+    def __init__(self, venv, actor, epsilon=0.0, obs_agent_id=True, seed=0):
+        self.venv, self.actor = venv, actor
+        self.epsilon = float(epsilon)
+        self.obs_agent_id = bool(obs_agent_id)
+        dev = venv.env.device
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(int(seed))
+        self.hidden = actor.init_hidden(venv.E).to(dev)
+        self._restart = torch.ones(venv.E, dtype=torch.uint8, device=dev)
+        venv.reset()
+
+    @torch.no_grad()
+    def run(self, T):
+        v, env, dev = self.venv, self.venv.env, self.venv.env.device
+        E, N, D, A = v.E, v.n_agents, v.obs_size, v.n_actions
+        out = {"obs": torch.empty(T + 1, E, N, D, device=dev), "state": torch.empty(T + 1, E, N * D, device=dev),
+               "avail_actions": torch.ones(T + 1, E, N, A, dtype=torch.int32, device=dev),
+               "actions": torch.empty(T, E, N, dtype=torch.int32, device=dev),
+               "reward": torch.empty(T, E, device=dev), "terminated": torch.empty(T, E, dtype=torch.bool, device=dev),
+               "episode_start": torch.empty(T, E, dtype=torch.bool, device=dev)}
+        fused = self.actor.fused_supported()
+        eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
+        for t in range(T):
+            obs = v.get_obs()                      # zeros right after a reset, like the reference's reset()
+            out["obs"][t] = obs
+            out["state"][t] = v.get_state()
+            out["episode_start"][t] = self._restart.bool()
+            if fused:
+                _, greedy = self.actor.forward_fused(obs.contiguous(), self.hidden, append_agent_id=self.obs_agent_id,
+                                                     restart=self._restart)
+            else:
+                h_in = torch.where(self._restart.bool()[:, None, None], torch.zeros_like(self.hidden), self.hidden)
+                q, h = self.actor.forward(torch.cat([obs, eye], dim=2) if self.obs_agent_id else obs, h_in)
+                self.hidden.copy_(h)
+                greedy = q.argmax(dim=2).to(torch.int32)
+            if self.epsilon > 0.0:
+                explore = torch.rand(E, N, generator=self.gen, device=dev) < self.epsilon
+                rnd = torch.randint(0, A, (E, N), generator=self.gen, device=dev, dtype=torch.int32)
+                actions = torch.where(explore, rnd, greedy)
+            else:
+                actions = greedy
+            out["actions"][t] = actions
+            reward, ended, _ = v.step(actions.contiguous())
+            out["reward"][t] = reward
+            out["terminated"][t] = ended
+            self._restart.copy_(ended)
+        out["obs"][T] = v.get_obs()
+        out["state"][T] = v.get_state()
+        return out

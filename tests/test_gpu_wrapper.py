@@ -100,3 +100,36 @@ def test_gymma_single_env_types():
     assert done and info.get("TimeLimit.truncated")
     assert env.get_env_info()["n_actions"] == 5 and len(env.get_avail_actions()) == env.n_agents
     env.close()
+
+
+def test_batched_runner_collects_transitions():
+    """The time-major transition tensors of the batched runner: shapes, the gymma reductions, and
+    consistency with the env's own episode statistics."""
+    import torch
+    from marbler_amd.evaluate import BatchedActor
+    from marbler_amd.gymma import BatchedRunner, GymmaVecEnv
+    from test_gpu_actor import _random_actor
+    E, T = 128, 120
+    v = GymmaVecEnv("robotarium_gym:PredatorCapturePrey-v0", E, time_limit=1000, seed=3)
+    actor = BatchedActor(_random_actor(1, v.obs_size + v.n_agents, 64, v.n_actions, True, seed=2), v.n_agents,
+                         device=v.env.device)
+    runner = BatchedRunner(v, actor, epsilon=0.3, seed=1)
+    b = runner.run(T)
+    N, D, A = v.n_agents, v.obs_size, v.n_actions
+    assert tuple(b["obs"].shape) == (T + 1, E, N, D) and tuple(b["state"].shape) == (T + 1, E, N * D)
+    assert tuple(b["actions"].shape) == (T, E, N) and tuple(b["reward"].shape) == (T, E)
+    assert tuple(b["avail_actions"].shape) == (T + 1, E, N, A) and bool((b["avail_actions"] == 1).all())
+    assert int(b["actions"].min()) >= 0 and int(b["actions"].max()) < A
+    assert torch.equal(b["state"], b["obs"].reshape(T + 1, E, N * D))
+    # an episode starts where the previous step ended one (and at t = 0); its first observation is zeros
+    assert bool(b["episode_start"][0].all())
+    assert torch.equal(b["episode_start"][1:], b["terminated"][:-1])
+    assert bool((b["obs"][:-1][b["episode_start"]] == 0).all())
+    # the rewards of finished episodes add up to the env's own accumulators (shared reward: N x reward[0])
+    n_done = int(b["terminated"].sum())
+    assert n_done == int(v.env.done_count.sum()) and n_done > E
+    ret_env = float(v.env.done_return_sum.sum()) + float(v.env.ep_return.sum())
+    assert abs(float(b["reward"].sum()) / N - ret_env) < 1e-2 * max(1.0, abs(ret_env))
+    # a second call continues the same episodes
+    b2 = runner.run(10)
+    assert torch.equal(b2["episode_start"][0], b["terminated"][-1])
