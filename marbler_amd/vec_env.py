@@ -75,14 +75,28 @@ class VecRobotariumEnv(object):
         self.done_return_sum = torch.zeros(E, dtype=f32, device=dev)
         self.done_count = torch.zeros(E, dtype=i32, device=dev)
         self.done_steps_sum = torch.zeros(E, dtype=i32, device=dev)
-        # ---- step outputs (rg_step_io)
-        self.obs = torch.zeros(E, N, D, dtype=f32, device=dev)
-        self.reward = torch.zeros(E, N, dtype=f32, device=dev)
-        self.done_u8 = torch.zeros(E, dtype=u8, device=dev)
+        # ---- step outputs (rg_step_io): views of ONE allocation, so a host-side consumer (the single-env
+        # Wrapper) fetches everything a step returns with one device-to-host copy
+        sizes = [("obs", E * N * D * 4), ("reward", E * N * 4), ("dist_travelled", E * N * 4), ("remaining", E * 4),
+                 ("done_u8", E), ("violation", E)]
+        offs, total = {}, 0
+        for name, nbytes in sizes:
+            offs[name] = total
+            total += (nbytes + 15) // 16 * 16
+        self._out_arena = torch.zeros(total, dtype=u8, device=dev)
+        self._out_offsets = offs
+
+        def view(name, nbytes, dtype, shape):
+            return self._out_arena[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
+
+        self.obs = view("obs", E * N * D * 4, f32, (E, N, D))
+        self.reward = view("reward", E * N * 4, f32, (E, N))
+        self.dist_travelled = view("dist_travelled", E * N * 4, f32, (E, N))
+        self.remaining = view("remaining", E * 4, i32, (E,))
+        self.remaining.fill_(-1)
+        self.done_u8 = view("done_u8", E, u8, (E,))
         self.done = self.done_u8.view(torch.bool)   # the same bytes (the kernel writes 0 / 1): no conversion launch per step
-        self.dist_travelled = torch.zeros(E, N, dtype=f32, device=dev)
-        self.violation = torch.zeros(E, dtype=u8, device=dev)
-        self.remaining = torch.full((E,), -1, dtype=i32, device=dev)
+        self.violation = view("violation", E, u8, (E,))
         self.qp_sweeps = torch.zeros(E, dtype=i32, device=dev) if collect_qp_stats else None
 
         self._stream = torch.cuda.current_stream(dev)
