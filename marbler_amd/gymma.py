@@ -135,42 +135,39 @@ class GymmaEnv(object):
         self._v.env.auto_reset = False
         self.n_agents = self._v.n_agents
         self.episode_limit = self._v.episode_limit
-        self._done = False
+        self._obs_host = np.zeros((self.n_agents, self._v.obs_size), np.float32)
+        self._elapsed_host = 0
 
     def step(self, actions):
-        a = torch.as_tensor(np.asarray([int(x) for x in actions], dtype=np.int32).reshape(1, -1),
-                            device=self._v.env.device)
-        obs, reward, done, info = self._v.env.step(a)
-        self._v._elapsed += 1
-        truncated = bool(self._v._elapsed[0] >= self.episode_limit) and not bool(done[0])
-        self._v._obs = obs
+        obs, reward, done, viol, _, _ = self._v.env.host_step([int(x) for x in actions])   # one upload, one download
+        self._obs_host = obs.copy()
+        self._elapsed_host += 1
+        truncated = self._elapsed_host >= self.episode_limit and not done
         out = {}
         if truncated:
             out["TimeLimit.truncated"] = True
-        viol = int(info["violation"][0])
         if viol:
             from .vec_env import VIOLATION_MESSAGES
             out["message"] = VIOLATION_MESSAGES[viol]
-        return float(reward[0].sum()), bool(done[0]) or truncated, out
+        return float(reward.sum()), done or truncated, out
 
     def reset(self):
         self._v.env.reset()
-        self._v._obs = self._v.env.obs
-        self._v._elapsed.zero_()
+        self._obs_host = np.zeros((self.n_agents, self._v.obs_size), np.float32)   # the reference's reset() observation
+        self._elapsed_host = 0
         return self.get_obs(), self.get_state()
 
     def get_obs(self):
-        o = self._v._obs[0].cpu().numpy()
-        return [o[i] for i in range(self.n_agents)]
+        return [self._obs_host[i] for i in range(self.n_agents)]
 
     def get_obs_agent(self, agent_id):
-        return self._v._obs[0, agent_id].cpu().numpy()
+        return self._obs_host[agent_id]
 
     def get_obs_size(self):
         return self._v.get_obs_size()
 
     def get_state(self):
-        return self._v._obs[0].reshape(-1).cpu().numpy()
+        return self._obs_host.reshape(-1)
 
     def get_state_size(self):
         return self._v.get_state_size()

@@ -158,6 +158,36 @@ class VecRobotariumEnv(object):
     def info(self):
         return {"dist_travelled": self.dist_travelled, "violation": self.violation, "remaining": self.remaining}
 
+    def host_step(self, actions):
+        """One step of a single-env object (E == 1) for host-side consumers (the reference-typed Wrapper,
+        EPyMARL's gymma shape): the actions go up through one pinned buffer, everything the step returns
+        comes down with ONE copy of the output allocation.  Returns NumPy views of that host copy
+        (obs [N,D] f32, reward [N] f32, done bool, violation int, remaining int, dist_travelled [N] f32),
+        valid until the next call."""
+        if self.E != 1:
+            raise ValueError("host_step is the single-env path (num_envs == 1)")
+        import numpy as np
+        if getattr(self, "_hs", None) is None:
+            o, N, D = self._out_offsets, self.N, self.D
+            host = torch.zeros_like(self._out_arena, device="cpu").pin_memory()
+            n = host.numpy()
+            self._hs = {"act_host": torch.zeros(1, N, dtype=torch.int32).pin_memory(),
+                        "act_dev": torch.zeros(1, N, dtype=torch.int32, device=self.device), "host": host,
+                        "obs": n[o["obs"]:o["obs"] + N * D * 4].view(np.float32).reshape(N, D),
+                        "reward": n[o["reward"]:o["reward"] + N * 4].view(np.float32),
+                        "dist": n[o["dist_travelled"]:o["dist_travelled"] + N * 4].view(np.float32),
+                        "remaining": n[o["remaining"]:o["remaining"] + 4].view(np.int32),
+                        "done": n[o["done_u8"]:o["done_u8"] + 1], "viol": n[o["violation"]:o["violation"] + 1]}
+        hs = self._hs
+        hs["act_host"].numpy()[0, :] = np.asarray(actions, dtype=np.int32).reshape(self.N)
+        hs["act_dev"].copy_(hs["act_host"], non_blocking=True)
+        rc = self.step_raw(hs["act_dev"].data_ptr())
+        if rc != 0:
+            _lib.check(rc, "rg_step")
+        hs["host"].copy_(self._out_arena, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return hs["obs"], hs["reward"], bool(hs["done"][0]), int(hs["viol"][0]), int(hs["remaining"][0]), hs["dist"]
+
     def step_raw(self, actions_ptr):
         """Hot-loop entry: one rg_step on a pre-validated device pointer to int32 [E,N]; results are
         in self.obs / reward / done_u8 / dist_travelled / violation / remaining."""

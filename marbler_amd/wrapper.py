@@ -33,19 +33,6 @@ class _ScenarioFacade(object):
         self.num_robots = self.vec.N
         self.action_space, self.observation_space = scenario_spaces(env_name, self.vec.params)
         self._scenario = env_name
-        # host side of a step: actions go up through one pinned buffer, everything a step returns comes
-        # down with ONE copy of the env's output allocation (vec_env.py: the outputs are views of it)
-        v = self.vec
-        self._act_host = torch.zeros(1, v.N, dtype=torch.int32).pin_memory()
-        self._act_dev = torch.zeros(1, v.N, dtype=torch.int32, device=v.device)
-        self._out_host = torch.zeros_like(v._out_arena, device="cpu").pin_memory()
-        o, n, N, D = v._out_offsets, self._out_host.numpy(), v.N, v.D
-        self._h_obs = n[o["obs"]:o["obs"] + N * D * 4].view(np.float32).reshape(N, D)
-        self._h_rew = n[o["reward"]:o["reward"] + N * 4].view(np.float32)
-        self._h_dist = n[o["dist_travelled"]:o["dist_travelled"] + N * 4].view(np.float32)
-        self._h_rem = n[o["remaining"]:o["remaining"] + 4].view(np.int32)
-        self._h_done = n[o["done_u8"]:o["done_u8"] + 1]
-        self._h_viol = n[o["violation"]:o["violation"] + 1]
 
     @property
     def agent_poses(self):
@@ -62,26 +49,15 @@ class _ScenarioFacade(object):
         return [[0] * self.vec.D] * self.num_robots
 
     def step(self, actions_):
-        v = self.vec
-        self._act_host.numpy()[0, :] = np.asarray(actions_, dtype=np.int32).reshape(self.num_robots)
-        self._act_dev.copy_(self._act_host, non_blocking=True)
-        rc = v.step_raw(self._act_dev.data_ptr())
-        if rc != 0:
-            from . import _lib
-            _lib.check(rc, "rg_step")
-        self._out_host.copy_(v._out_arena, non_blocking=True)
-        torch.cuda.current_stream(v.device).synchronize()
-        obs = self._h_obs.astype(np.float64)
-        terminated = bool(self._h_done[0])
+        h_obs, h_rew, terminated, viol, rem, h_dist = self.vec.host_step(actions_)
+        obs = h_obs.astype(np.float64)
         out = {}
-        viol = int(self._h_viol[0])
         if viol:
             out["message"] = VIOLATION_MESSAGES[viol]
-        rem = int(self._h_rem[0])
         if rem >= 0:
             out["remaining"] = rem
-        out["dist_travelled"] = self._h_dist.astype(np.float64)
-        return [obs[i] for i in range(self.num_robots)], [float(r) for r in self._h_rew], \
+        out["dist_travelled"] = h_dist.astype(np.float64)
+        return [obs[i] for i in range(self.num_robots)], [float(r) for r in h_rew], \
             [terminated] * self.num_robots, out
 
     def render(self, mode='human'):
