@@ -128,14 +128,17 @@ def cpu_baseline(seconds_budget=12.0):
     for k in range(40):
         env.step(acts[k])
     c_rate = 40 * E * 5 / (time.perf_counter() - t0)
-    all_rate, n_proc = cpu_all_cores()
+    # under rocprofv3 the profiler's preloaded library has already initialised the GPU in this process:
+    # no child processes then (each would be an exec after GPU initialisation)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ)
+    all_rate, n_proc = (None, 0) if profiled else cpu_all_cores()
     return {"value": py_rate, "unit": "agent-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} env-steps of 1 env x 5 agents, NumPy float64 port in the reference's shape "
                       f"(oracle/np_port.py), {dt:.1f} s on one core",
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
             "all_cores": {"value": all_rate, "cores": n_proc, "kind": "port",
                           "sample": f"{n_proc} processes x 1 env each (EPyMARL parallel-runner shape; one GPU's share of "
-                                    f"the host cores), 8 s"},
+                                    f"the host cores), 8 s" if not profiled else "skipped under rocprofv3 (no child processes)"},
             "c_oracle_f64_1core": c_rate}
 
 
