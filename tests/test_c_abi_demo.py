@@ -36,7 +36,10 @@ def test_c_demo_compiles_and_links_against_the_header():
 
 @pytest.mark.gpu
 def test_c_demo_steps_envs_from_plain_c():
-    _build()   # child processes are started before this test process touches the GPU itself
+    import torch
+    if torch.cuda.is_initialized():   # never start a program from a process that has initialised the GPU
+        pytest.skip("this process already uses the GPU; run tests/test_c_abi_demo.py on its own")
+    _build()
     r = subprocess.run([EXE, PARAMS, "2048", "300"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     m = re.search(r"C_ABI_DEMO scenario 0 envs 2048 agents 5 steps 300 : ([0-9.]+) us per step, ([0-9.]+) M agent-steps/s, "
