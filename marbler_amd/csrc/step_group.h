@@ -1044,7 +1044,10 @@ static hipError_t launch_step_scn(const KernelArgs &a_in, hipStream_t stream) {
     KernelArgs a = a_in;
     int epw = WAVE / gw;
 #ifndef RG_STAMPS
-    while (epw >= 2 && (a.E + epw / 2 - 1) / (epw / 2) <= 1024) epw /= 2;
+#ifndef RG_MAX_WAVES
+#define RG_MAX_WAVES 1024
+#endif
+    while (epw >= 2 && (a.E + epw / 2 - 1) / (epw / 2) <= RG_MAX_WAVES) epw /= 2;
     a.envs_per_wave = epw;
 #endif
     const int grid = (a.E + epw - 1) / epw;
