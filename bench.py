@@ -63,13 +63,35 @@ def _port_worker(seconds, seed):
     print(f"PORT_STEPS {n} {time.perf_counter() - t0:.3f}")
 
 
-def cpu_all_cores(seconds=8.0):
+def _oracle_worker(seconds, seed):
+    """The C oracle (float64, 512 envs batched) stepped for `seconds` on this process's core."""
+    import numpy as np
+    from oracle import np_port
+    from oracle.c_oracle import OracleVecEnv
+    from marbler_amd.params import load_config
+    cfg = load_config("PredatorCapturePrey", overrides=dict(PCP_OVERRIDES, seed=seed))
+    port = np_port.make_port("PredatorCapturePrey", cfg)
+    E = 512
+    env = OracleVecEnv("PredatorCapturePrey", cfg, E, dtype=np.float64)
+    for e in range(E):
+        port.reset()
+        env.set_state(e, poses=port.agent_poses, prey_loc=port.prey_loc)
+    rng = np.random.RandomState(seed)
+    acts = rng.randint(0, 5, size=(8, E, 5)).astype(np.int32)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        env.step(acts[n % 8])
+        n += 1
+    print(f"PORT_STEPS {n * E} {time.perf_counter() - t0:.3f}")
+
+
+def cpu_all_cores(seconds=8.0, worker="_port_worker"):
     """the same port, one env per process, one process per host core (the shape of
     EPyMARL's parallel runner).  CPU-only child processes; returns (agent-steps/s, processes)."""
     import subprocess
     n = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))   # one GPU's share of the host: 16 cores
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
-    code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench._port_worker({seconds}, int(sys.argv[1]))"
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.{worker}({seconds}, int(sys.argv[1]))"
     procs = [subprocess.Popen([sys.executable, "-c", code, str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                               text=True, env=env) for i in range(n)]
     rate = 0.0
@@ -132,6 +154,7 @@ def cpu_baseline(seconds_budget=12.0):
     # no child processes then (each would be an exec after GPU initialisation)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ)
     all_rate, n_proc = (None, 0) if profiled else cpu_all_cores()
+    c_all, _ = (None, 0) if profiled else cpu_all_cores(4.0, "_oracle_worker")
     return {"value": py_rate, "unit": "agent-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} env-steps of 1 env x 5 agents, NumPy float64 port in the reference's shape "
                       f"(oracle/np_port.py), {dt:.1f} s on one core",
@@ -139,7 +162,7 @@ def cpu_baseline(seconds_budget=12.0):
             "all_cores": {"value": all_rate, "cores": n_proc, "kind": "port",
                           "sample": f"{n_proc} processes x 1 env each (EPyMARL parallel-runner shape; one GPU's share of "
                                     f"the host cores), 8 s" if not profiled else "skipped under rocprofv3 (no child processes)"},
-            "c_oracle_f64_1core": c_rate}
+            "c_oracle_f64_1core": c_rate, "c_oracle_f64_all_cores": {"value": c_all, "cores": n_proc}}
 
 
 SATURATED_ENVS = 524288
