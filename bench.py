@@ -23,6 +23,8 @@ ENVS_PER_GPU = 4096
 PCP_OVERRIDES = {"predator": 3, "capture": 2, "n_agents": 5}   # BASELINE: 5 agents
 # algorithmic bytes per env-step of a fully fused PCP step (N=5, D=16, P=6)
 ALGO_BYTES_PER_ENV_STEP = 585
+# the same for the other BASELINE configurations (Warehouse N=8, D=18; MaterialTransport N=6, D=9)
+ALGO_BYTES_OTHER = {"Warehouse": 896, "MaterialTransport": 510}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -325,7 +327,8 @@ def main():
     if rank == 0:
         total_agent_steps = world * E * N * K
         value = total_agent_steps / elapsed
-        bytes_per_launch = ALGO_BYTES_PER_ENV_STEP * E if args.scenario == "PredatorCapturePrey" else None
+        bytes_per_launch = (ALGO_BYTES_PER_ENV_STEP if args.scenario == "PredatorCapturePrey"
+                            else ALGO_BYTES_OTHER[args.scenario]) * E
         achieved = bytes_per_launch / (gpu_ms_total / K * 1e-3) / 1e9 if bytes_per_launch else None
         traffic, traffic_src = measured_traffic() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU) \
             else (None, None)
@@ -339,8 +342,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "rg::step_kernel<PCP,GW=8,N=5> (lane group per env)" if E < 40960
-                                   else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)",
+                         "kernel": (f"rg::step_kernel<{args.scenario},GW={4 if N <= 4 else 8 if N <= 8 else 16},N={N}> (lane group per env)"
+                                    if (args.scenario != "PredatorCapturePrey" or E < 40960)
+                                    else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)"),
                          "kernel_ms_avg": gpu_ms_total / K,   # HIP events around the timed region / K (back-to-back launches)
                          "kernel_ms_avg_event_pair_per_launch": kernel_ms,
                          "kernel_ms_median_event_pair_per_launch": kernel_ms_median,
