@@ -70,3 +70,39 @@ def test_evaluate_cli_on_a_model_zoo_shaped_checkpoint(tmp_path):
     assert fused["episodes"] >= 96 and 0 < fused["mean_steps"] <= 81 and np.isfinite(fused["mean_return"])
     # same policy, float32 both ways: the two evaluations may part ways only through 1e-6-level ties in arg-max
     assert abs(fused["mean_return"] - eager["mean_return"]) < 1.0 and abs(fused["episodes"] - eager["episodes"]) <= 10
+
+
+ZOO = "/root/reference/robotarium_gym/scenarios"
+
+
+@pytest.mark.skipif(not os.path.isdir(ZOO), reason="the reference tree (with its model zoo) is not on this machine")
+def test_every_model_of_the_reference_zoo_loads_and_fits_its_scenario():
+    """misc.py:65-91 without the env: each `.th` / `.json` pair of the reference's model zoo loads into
+    BatchedActor (shared and non-shared, GRU and MLP), its input width is the scenario's observation
+    width (+ agent id) under this package's copy of that scenario's config, its action count is the
+    scenario's, and its shape is one the fused kernel takes.  (Read here only; nothing of the zoo is
+    copied into the repo.)"""
+    import json
+    from marbler_amd.evaluate import load_actor
+    from marbler_amd.gymma import N_ACTIONS
+    from marbler_amd.params import load_config, make_params
+    seen = 0
+    for scenario in sorted(os.listdir(ZOO)):
+        mdir = os.path.join(ZOO, scenario, "models")
+        if scenario not in N_ACTIONS or not os.path.isdir(mdir):
+            continue
+        p = make_params(scenario, load_config(scenario))
+        for js in sorted(glob.glob(os.path.join(mdir, "*.json"))):
+            th = js[:-5] + ".th"
+            if not os.path.exists(th):
+                continue
+            actor, cfg = load_actor(th, js, p.n_agents, device="cpu")
+            width = p.obs_dim + (p.n_agents if cfg.get("obs_agent_id", True) else 0)
+            assert actor.input_dim == width, (scenario, os.path.basename(js), actor.input_dim, width)
+            assert actor.n_actions == N_ACTIONS[scenario], (scenario, os.path.basename(js))
+            assert actor.hidden_dim in (64, 128) and actor.n_actions <= 32 and actor.input_dim <= 64
+            assert actor.non_shared == (cfg.get("agent") == "rnn_ns")
+            q, h = actor.forward(torch.zeros(2, p.n_agents, width), actor.init_hidden(2))
+            assert tuple(q.shape) == (2, p.n_agents, actor.n_actions) and torch.isfinite(q).all()
+            seen += 1
+    assert seen >= 15
