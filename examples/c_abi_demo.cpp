@@ -96,7 +96,7 @@ int main(int argc, char **argv) {
         return 3;
     }
     RG_OK(rg_bind_state(h, &st));
-    RG_OK(rg_reset(h, nullptr, /*seed=*/0));
+    RG_OK(rg_reset(h, nullptr, /*seed=*/0, /*flags=*/0));
 
     // a random policy: a few batches of actions, generated on the host once and cycled
     const int n_act = p.scenario == RG_SCN_MATERIAL_TRANSPORT ? 20 : 5, n_batches = 16;

@@ -11,6 +11,9 @@
  *    owned by the caller (torch-ROCm tensors: `tensor.data_ptr()`).  The library never allocates
  *    or frees caller-visible memory.
  *  - All calls are asynchronous on the HIP stream given to rg_create; no call synchronises.
+ *  - Every call on a handle runs with the handle's device current (hipSetDevice(device of rg_create))
+ *    and restores the caller's current device before returning: a handle created for GPU 1 launches
+ *    on GPU 1 whatever device the calling thread has selected.  The stream must belong to that device.
  *  - Return value: 0 = OK, negative = error (text via rg_last_error()).  No exceptions cross
  *    the ABI.  A handle is re-entrant across handles, not thread-safe within one.
  *  - E envs, N agents per env, P prey, D per-agent observation length.
@@ -24,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 2
+#define RG_ABI_VERSION 3
 #define RG_MAX_AGENTS 16
 #define RG_MAX_PREY 64
 
@@ -158,8 +161,13 @@ int rg_bind_state(rg_handle *h, const rg_state *state);
 
 /* Replaces scenario.reset() + roboEnv.reset() (PredatorCapturePrey.py:114-136, warehouse.py:84-100,
  * MaterialTransport.py:94-111, roboEnv.py:27-36,98-118, misc.py:49-63).  mask: [E] uint8 device
- * pointer, nonzero = reset that env; NULL = all. */
-int rg_reset(rg_handle *h, const uint8_t *mask, uint64_t seed);
+ * pointer, nonzero = reset that env; NULL = all.
+ * The running return of a reset env (rg_state.ep_return) restarts at zero.  flags:
+ * RG_RESET_BOOK_EPISODE -- the abandoned episode (if it has taken at least one step) is first added to
+ * done_return_sum / done_count / done_steps_sum, as an episode that a time limit outside the scenario
+ * cut short (gym's TimeLimit in EPyMARL's gymma wrapper; `run_env` counts such episodes, misc.py:186-206). */
+#define RG_RESET_BOOK_EPISODE 1
+int rg_reset(rg_handle *h, const uint8_t *mask, uint64_t seed, int32_t flags);
 
 /* Replaces Wrapper.step -> scenario.step -> roboEnv.step -> Controller.set_velocities ->
  * rps.Robotarium.{get_poses,set_velocities,step} and the scenario's tracking / observation /

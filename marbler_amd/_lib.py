@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 MAX_AGENTS, MAX_PREY = 16, 64
-ABI_VERSION = 2
+ABI_VERSION = 3
+RESET_BOOK_EPISODE = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROBOGYM_LIB") or os.path.join(_HERE, "librobogym_hip.so")  # override: diagnostic builds
@@ -106,7 +107,7 @@ def load():
     lib.rg_destroy.argtypes = [C.c_void_p]
     lib.rg_bind_state.argtypes = [C.c_void_p, C.POINTER(RgState)]
     lib.rg_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-    lib.rg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.rg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]
     lib.rg_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RgStepIO), C.c_int32, C.c_uint64]
     lib.rg_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(RgStepIO), C.c_int32, C.c_uint64]
     lib.rg_get_obs.argtypes = [C.c_void_p, C.c_void_p]

@@ -16,6 +16,23 @@ namespace rg {
 constexpr int WAVE = 64;
 constexpr int MAX_DRAWS = 128;  // u32 draws per reset: 4 + 2N + P <= 4 + 32 + 64, rounded up to blocks
 
+// ------------------------------------------------------------------ workgroup -> env chunk (XCD-aware)
+// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.  With
+// chunk = b, neighbouring env chunks -- whose state and output spans share 128-byte lines wherever a span
+// is not a multiple of the line (5 agents: 60-byte pose blocks, 20-byte reward rows, 1-byte done flags) --
+// land on different L2s: every shared line is fetched by two XCDs and written back as two partial lines.
+// Instead XCD x works through ONE contiguous run of chunks, so shared lines meet in one L2 (measured with
+// rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/).  Affinity only: results do not depend on the block -> XCD map.
+__device__ __forceinline__ int xcd_chunk() {
+#ifdef RG_NO_XCD_REMAP  // diagnostic builds (A/B traffic measurements)
+    return blockIdx.x;
+#endif
+    const int b = blockIdx.x, G = gridDim.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int q = G >> 3, r = G & 7;
+    return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
 // ------------------------------------------------------------------ lane exchange (DPP)
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {

@@ -73,6 +73,7 @@ struct KernelArgs {
     int32_t envs_per_wave; // lane-group kernel: env slots used per wavefront (0 = all 64/GW; fewer for small batches, see launch_step_scn)
     int32_t num_steps;  // env steps per launch (rg_step: 1); io and actions carry a leading dimension of this size
     int32_t auto_reset;
+    int32_t reset_flags;  // rg_reset: RG_RESET_*
     int64_t env_offset;
     uint64_t seed;
 };

@@ -43,6 +43,25 @@ static int32_t tpe_min_envs(const rg_scenario_params &p) {
 
 static thread_local char g_err[512] = "";
 
+// The handle's device is current for the duration of a call; the caller's device is restored on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 static int fail(int code, const char *fmt, const char *detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
     return code;
@@ -199,11 +218,18 @@ static int launched(hipError_t err) {
     return 0;
 }
 
-int rg_reset(rg_handle *h, const uint8_t *mask, uint64_t seed) {
+#define RG_ON_DEVICE(h)                                                                           \
+    DeviceGuard guard_((h)->device);                                                              \
+    if (guard_.err != hipSuccess) return fail(-31, "cannot select the handle's device: %s", hipGetErrorString(guard_.err))
+
+int rg_reset(rg_handle *h, const uint8_t *mask, uint64_t seed, int32_t flags) {
     rg::KernelArgs a;
     if (int rc = fill_args(h, a)) return rc;
+    if (flags & ~RG_RESET_BOOK_EPISODE) return fail(-28, "unknown rg_reset flags");
     a.reset_mask = mask;
     a.seed = seed;
+    a.reset_flags = flags;
+    RG_ON_DEVICE(h);
     return launched(rg::launch_reset(a, h->stream));
 }
 
@@ -218,6 +244,7 @@ int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t 
     a.io = *io;
     a.auto_reset = auto_reset;
     a.seed = seed;
+    RG_ON_DEVICE(h);
     return launched(h->use_tpe ? rg::launch_step_tpe(a, h->stream) : rg::launch_step(a, false, h->stream));
 }
 
@@ -238,6 +265,7 @@ int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg
     a.num_steps = num_steps;
     a.auto_reset = auto_reset;
     a.seed = seed;
+    RG_ON_DEVICE(h);
     if (!h->use_tpe) return launched(rg::launch_rollout(a, h->stream));
     // thread-per-env: the multi-step kernel holds more values live (313 VGPRs at N = 5: one wave per
     // SIMD); it pays while the batch is at most one wave per SIMD (the latency regime), beyond that
@@ -260,6 +288,7 @@ int rg_get_obs(rg_handle *h, float *obs) {
     if (!obs) return fail(-23, "obs is NULL");
     if (reinterpret_cast<uintptr_t>(obs) & 15u) return fail(-26, "obs must be 16-byte aligned");
     a.io.obs = obs;
+    RG_ON_DEVICE(h);
     return launched(rg::launch_step(a, true, h->stream));
 }
 

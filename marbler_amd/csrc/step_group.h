@@ -269,7 +269,8 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     const int g = lane / GW;
     const int gbase = lane & ~(GW - 1);
     const int epw = a.envs_per_wave > 0 ? a.envs_per_wave : EPW;
-    const int e = blockIdx.x * epw + g;
+    const int chunk = xcd_chunk();
+    const int e = chunk * epw + g;
     const bool env_ok = (g < epw) & (e < a.E);
     const bool lane_ok = env_ok && ag < N;
     const size_t eN = static_cast<size_t>(e) * N;
@@ -426,6 +427,10 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
         bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
         float fin_x = 0.0f, fin_y = 0.0f;
+        // x, y = period base (bx, by) + displacement since the period began (ox, oy): a sub-step adds
+        // dt*v*(cos, sin) to the small displacement and the position is the single rounding bx + ox, so the
+        // roundings of the 29..74 Euler updates do not pile up in x, y (float spec, oracle/oracle_core.h)
+        float bx = x, by = y, ox = 0.0f, oy = 0.0f;
         const bool penalize = p.penalize_violations != 0;
         const int U = p.update_frequency, period = p.controller_period;
         for (int it0 = 0; it0 < U; it0 += period) {
@@ -451,7 +456,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             // C sub-steps starting at sub-step j0 of this period
             auto run_chunk = [&](auto CC, int j0) {
                 constexpr int C = decltype(CC)::value;
-                const float x0 = x, y0 = y, c0 = c, s0 = s;
+                const float x0 = x, y0 = y, ox0 = ox, oy0 = oy, c0 = c, s0 = s;
                 const bool live = lane_ok & !dead;
                 int q[C];
                 // every pre-update position of the chunk lies within (C-1)|dt v| of the first
@@ -462,8 +467,10 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     const int qr = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(fx, fy));
                     q[u] = live ? qr : ghost_q;
                     // Euler step (Appendix A.4); rotate (cos, sin) by dt*w
-                    x = __builtin_fmaf(c, dtv, x);
-                    y = __builtin_fmaf(s, dtv, y);
+                    ox = __builtin_fmaf(c, dtv, ox);
+                    oy = __builtin_fmaf(s, dtv, oy);
+                    x = bx + ox;
+                    y = by + oy;
                     const float cn = __builtin_fmaf(c, cd, -(s * sd));
                     const float sn = __builtin_fmaf(s, cd, c * sd);
                     c = cn;
@@ -498,7 +505,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     // boundary test on every sub-step (per lane, cheap), the pair rounds only on the sub-steps
                     // whose own pre-test fired somewhere in the wave (robots cross the 3 mm pre-test band
                     // within a sub-step or two: most sub-steps of a flagged chunk need no pair rounds)
-                    float rx = x0, ry = y0, rc = c0, rs = s0;
+                    float rx = x0, ry = y0, rox = ox0, roy = oy0, rc = c0, rs = s0;
                     static_for<0, C>([&](auto UU) {
                         constexpr int u = decltype(UU)::value;
                         const bool bnd = lane_ok & !dead & ((rx < k.xmin) | (rx > k.xmax) | (ry < k.ymin) | (ry > k.ymax));
@@ -526,8 +533,10 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                         }
                         col = col & lane_ok & !dead;
                         const int code = (group_any<GW>(col, gbase) ? 1 : 0) | (group_any<GW>(bnd, gbase) ? 2 : 0);
-                        rx = __builtin_fmaf(rc, dtv, rx);  // the violating sub-step is still integrated
-                        ry = __builtin_fmaf(rs, dtv, ry);
+                        rox = __builtin_fmaf(rc, dtv, rox);  // the violating sub-step is still integrated
+                        roy = __builtin_fmaf(rs, dtv, roy);
+                        rx = bx + rox;
+                        ry = by + roy;
                         if (env_ok & !dead & (code != 0)) {
                             viol = code;
                             n_exec = j0 + u + 1;
@@ -556,6 +565,13 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             th = upd ? wrap_spec(__builtin_fmaf(ne, dtw, th)) : th;
             acc = upd ? __builtin_fmaf(ne, adv, acc) : acc;
             last = upd ? adv : last;
+            {   // base <- base + displacement (= x, y as last formed); displacement <- the exact remainder (TwoSum)
+                const float tx = x - bx, ty = y - by;
+                ox = (bx - (x - tx)) + (ox - tx);
+                oy = (by - (y - ty)) + (oy - ty);
+                bx = x;
+                by = y;
+            }
             if (it0 == 0) RG_STAMP(2);  // first period done
             if (!__any(env_ok & !dead)) break;
         }
@@ -988,7 +1004,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         if (lane == 0 && sv.io.qp_sweeps) {
             stamps[7] = max_sweeps;
             for (int i = 0; i < 8; ++i)
-                if (blockIdx.x * EPW + i < a.E) sv.io.qp_sweeps[blockIdx.x * EPW + i] = stamps[i];
+                if (chunk * EPW + i < a.E) sv.io.qp_sweeps[chunk * EPW + i] = stamps[i];
         }
 #endif
     }
@@ -1024,7 +1040,19 @@ __global__ __launch_bounds__(WAVE) void reset_kernel(const KernelArgs a) {
     const bool env_ok = e < a.E;
     const bool want = env_ok && (a.reset_mask == nullptr || a.reset_mask[e] != 0);
     if (!__any(want)) return;
+    // the running return restarts with the episode; RG_RESET_BOOK_EPISODE first books the abandoned
+    // episode as finished (an episode cut short by a time limit outside the scenario)
+    const bool stats = want && ag == 0 && a.st.ep_return != nullptr;
+    const int steps_before = stats ? a.st.episode_steps[e] : 0;
     reset_group<SCN, GW>(a, lds, e, g, ag, want);
+    if (stats) {
+        if ((a.reset_flags & RG_RESET_BOOK_EPISODE) && steps_before > 0) {
+            a.st.done_return_sum[e] = a.st.done_return_sum[e] + a.st.ep_return[e];
+            a.st.done_count[e] = a.st.done_count[e] + 1;
+            a.st.done_steps_sum[e] = a.st.done_steps_sum[e] + steps_before;
+        }
+        a.st.ep_return[e] = 0.0f;
+    }
 }
 
 }  // namespace rg

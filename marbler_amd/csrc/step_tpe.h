@@ -319,6 +319,15 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     const int U = p.update_frequency, period = p.controller_period;
     const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
     float v[N], w[N], s[N], c[N];
+    // x, y = period base (bx, by) + displacement since the period began (ox, oy); see step_group.h
+    float bx[N], by[N], ox[N], oy[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        bx[i] = x[i];
+        by[i] = y[i];
+        ox[i] = 0.0f;
+        oy[i] = 0.0f;
+    }
     for (int it0 = 0; it0 < U && !viol; it0 += period) {
         const int n = (U - it0) < period ? (U - it0) : period;
 #pragma unroll
@@ -355,11 +364,13 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             });
             return code;
         };
-        auto advance = [&](float (&ax)[N], float (&ay)[N], float (&ac)[N], float (&as)[N]) {
+        auto advance = [&](float (&ax)[N], float (&ay)[N], float (&aox)[N], float (&aoy)[N], float (&ac)[N], float (&as)[N]) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                ax[i] = __builtin_fmaf(ac[i], dtv[i], ax[i]);
-                ay[i] = __builtin_fmaf(as[i], dtv[i], ay[i]);
+                aox[i] = __builtin_fmaf(ac[i], dtv[i], aox[i]);
+                aoy[i] = __builtin_fmaf(as[i], dtv[i], aoy[i]);
+                ax[i] = bx[i] + aox[i];
+                ay[i] = by[i] + aoy[i];
                 const float cn = __builtin_fmaf(ac[i], cd[i], -(as[i] * sd[i]));
                 const float sn = __builtin_fmaf(as[i], cd[i], ac[i] * sd[i]);
                 ac[i] = cn;
@@ -369,11 +380,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         // C sub-steps starting at sub-step j0; returns false when the env hit a violation
         auto run_chunk = [&](auto CC, int j0) -> bool {
             constexpr int C = decltype(CC)::value;
-            float x0[N], y0[N], c0[N], s0[N];
+            float ox0[N], oy0[N], c0[N], s0[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                x0[i] = x[i];
-                y0[i] = y[i];
+                ox0[i] = ox[i];
+                oy0[i] = oy[i];
                 c0[i] = c[i];
                 s0[i] = s[i];
             }
@@ -398,7 +409,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                     const int d2 = dot2_bits(dq);
                     dmin = d2 < dmin ? d2 : dmin;
                 });
-                advance(x, y, c, s);
+                advance(x, y, ox, oy, c, s);
             });
             if (penalize && ((dmin <= thr_pre) | bnd_any)) {
 #ifdef RG_TPE_DIAG
@@ -407,14 +418,16 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    x[i] = x0[i];
-                    y[i] = y0[i];
+                    ox[i] = ox0[i];
+                    oy[i] = oy0[i];
+                    x[i] = bx[i] + ox[i];
+                    y[i] = by[i] + oy[i];
                     c[i] = c0[i];
                     s[i] = s0[i];
                 }
                 for (int u = 0; u < C; ++u) {
                     const int code = validate(x, y, c, s);
-                    advance(x, y, c, s);  // the violating sub-step is still integrated
+                    advance(x, y, ox, oy, c, s);  // the violating sub-step is still integrated
                     if (code) {
                         viol = code;
                         n_exec = j0 + u + 1;
@@ -438,6 +451,12 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             th[i] = wrap_spec(__builtin_fmaf(ne, dtw[i], th[i]));
             acc[i] = __builtin_fmaf(ne, adv, acc[i]);
             last[i] = adv;
+            // base <- base + displacement (= x, y as last formed); displacement <- the exact remainder (TwoSum)
+            const float tx = x[i] - bx[i], ty = y[i] - by[i];
+            ox[i] = (bx[i] - (x[i] - tx)) + (ox[i] - tx);
+            oy[i] = (by[i] - (y[i] - ty)) + (oy[i] - ty);
+            bx[i] = x[i];
+            by[i] = y[i];
         }
     }
     float dist[N];
@@ -791,7 +810,8 @@ template <int SCN, int N, bool ROLLOUT>
 // and measured 1.7x slower; the natural allocation runs 2 waves per SIMD at N = 5, 6 and 3 at N <= 4)
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ Lds<WAVE> lds;
-    const int e = blockIdx.x * WAVE + threadIdx.x;
+    const int chunk = xcd_chunk();
+    const int e = chunk * WAVE + threadIdx.x;
     const int num_steps = ROLLOUT ? a.num_steps : 1;  // rg_rollout: no device-wide synchronisation between steps
     for (int t = 0; t < num_steps; ++t) {
         if (t) __syncthreads();  // the previous step's stores and resets are visible to the wave
@@ -805,7 +825,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             while (todo) {
                 const int i = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                reset_group<SCN, WAVE>(a, lds, blockIdx.x * WAVE + i, 0, threadIdx.x, true);
+                reset_group<SCN, WAVE>(a, lds, chunk * WAVE + i, 0, threadIdx.x, true);
             }
         }
     }

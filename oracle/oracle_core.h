@@ -441,11 +441,24 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
      *    becomes carry_out; on a violation the last one is included (roboEnv.py:93);
      *  - theta advances n*dt*w in one fma and is wrapped once per period;
      *  - within a period sin/cos of the heading advance by the rotation (cos, sin)(dt*w) instead
-     *    of being re-evaluated; x, y and the collision offset point use explicit fma. */
+     *    of being re-evaluated; the collision offset point uses explicit fma;
+     *  - x, y are kept as a period base (bx, by) plus the displacement since the period began
+     *    (ox, oy: |.| <= 15 * 0.0066 m, so its roundings are ~16x finer than those of a coordinate
+     *    near 1 m): a sub-step adds dt*v*(cos, sin) to the displacement with one fma and the
+     *    position of sub-step j is the single rounding bx + ox -- rounding errors of the 29..74
+     *    Euler updates do not pile up in x, y (they did, and a reversing unicycle amplifies them:
+     *    measured 7x smaller |x - x_f64| per step, tests/golden/PARITY_REPORT.json).  At a period
+     *    end the base moves to bx + ox and the exact remainder of that addition (TwoSum) seeds the
+     *    next period's displacement. */
     REAL acc[ORC_MAXN], dtv[ORC_MAXN], dtw[ORC_MAXN], cd[ORC_MAXN], sd[ORC_MAXN], last[ORC_MAXN];
+    REAL bx[ORC_MAXN], by[ORC_MAXN], ox[ORC_MAXN], oy[ORC_MAXN];
     for (int a = 0; a < N; ++a) {
         acc[a] = st->carry[(size_t)e * N + a];
         last[a] = R(0);
+        bx[a] = x[a];
+        by[a] = y[a];
+        ox[a] = R(0);
+        oy[a] = R(0);
     }
     for (int it0 = 0; it0 < p->update_frequency && !viol; it0 += p->controller_period) {
         int n = p->update_frequency - it0;
@@ -462,8 +475,10 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
         for (int j = 0; j < n; ++j) {
             int code = FN(validate)(p, N, x, y, cs, ss);
             for (int a = 0; a < N; ++a) {
-                x[a] = __builtin_fmaf(cs[a], dtv[a], x[a]);
-                y[a] = __builtin_fmaf(ss[a], dtv[a], y[a]);
+                ox[a] = __builtin_fmaf(cs[a], dtv[a], ox[a]);
+                oy[a] = __builtin_fmaf(ss[a], dtv[a], oy[a]);
+                x[a] = bx[a] + ox[a];
+                y[a] = by[a] + oy[a];
                 REAL cn = __builtin_fmaf(cs[a], cd[a], -(ss[a] * sd[a]));
                 REAL sn = __builtin_fmaf(ss[a], cd[a], cs[a] * sd[a]);
                 cs[a] = cn;
@@ -479,6 +494,12 @@ static void FN(step_env)(const orc_params *p, int e, const FN(orc_state) * st, c
             last[a] = __builtin_fabsf(dtv[a]);
             th[a] = WRAP(__builtin_fmaf((REAL)n_exec, dtw[a], th[a]));
             acc[a] = __builtin_fmaf((REAL)n_exec, last[a], acc[a]);
+            /* base <- base + displacement (= x, y as last formed); displacement <- the exact remainder */
+            REAL tx = x[a] - bx[a], ty = y[a] - by[a];
+            ox[a] = (bx[a] - (x[a] - tx)) + (ox[a] - tx);
+            oy[a] = (by[a] - (y[a] - ty)) + (oy[a] - ty);
+            bx[a] = x[a];
+            by[a] = y[a];
         }
     }
     for (int a = 0; a < N; ++a) {

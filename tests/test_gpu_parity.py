@@ -1,12 +1,13 @@
 """GPU parity (the -m gpu tier): the HIP step kernels, called through the C ABI, against
   (1) the float32 oracle (oracle/oracle.c, tier 3)  -- BIT-EXACT on every output and on the state,
-  (2) the golden vectors captured from the reference's own Python (float64) -- masks exact,
-      observations / rewards / dist / xy within 1e-5 (2e-5 for U = 74), teacher-forced per step.
+  (2) the golden vectors captured from the reference's own Python (float64) -- the bar of
+      tests/parity.py: masks exact, observations / rewards / dist / xy within 1e-5 in every scenario,
+      headings within the committed per-fixture bound, near-tie rows explained one by one.
 """
 import numpy as np
 import pytest
 
-from helpers import angle_diff, golden_files, gpu_from_state, load_golden, oracle_from_state, pre_state
+from helpers import golden_files, gpu_from_state, load_golden, oracle_from_state, pre_state
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("step_kernel")]
 
@@ -49,23 +50,20 @@ def test_step_bit_exact_vs_f32_oracle(path, oracle_lib):
 
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
 def test_step_vs_reference_golden(path):
+    """The bar of tests/parity.py against the reference's own vectors: masks exact; x, y, dist, rewards and
+    observations within 1e-5 in EVERY scenario (74 sub-steps included); headings within 2x the maximum
+    measured for the fixture (PARITY_REPORT.json); an observation row over 1e-5 must be explained by a
+    float64 near-tie of the neighbour order / nearest prey -- zero unexplained rows."""
+    import os
+    import parity
     g, scenario, cfg = load_golden(path)
-    state = pre_state(g)
-    out, post = _run_gpu(scenario, cfg, state, g["actions"])
-    tol = 2e-5 if cfg["update_frequency"] > 29 else 1e-5
-    assert np.array_equal(out["viol"], g["viol"])
-    assert np.array_equal(out["done"], g["done"])
-    assert np.array_equal(out["remaining"], g["remaining"])
-    assert np.abs(out["reward"] - g["reward"]).max() <= 1e-5
-    assert np.abs(out["dist"] - g["dist"]).max() <= tol
-    assert np.abs(post["poses"][:, :2] - g["post_poses"][:, :2]).max() <= tol
-    # headings: reversing robots amplify rounding (DESIGN.md "float32 vs float64"); bound, not 1e-5
-    assert angle_diff(post["poses"][:, 2], g["post_poses"][:, 2]).max() <= 5e-4
-    for k in ("prey_sensed", "prey_captured", "loaded", "load", "zone_load", "messages", "pixel_type", "reached_goal"):
-        if "post_" + k in g.files:
-            assert np.array_equal(post[k], g["post_" + k]), k
-    # observations: rows whose neighbour order / nearest prey hinges on a float32 near-tie are
-    # compared as a multiset of blocks; everything else element-wise
-    d = np.abs(out["obs"] - g["obs"])
-    bad = d.max(axis=2) > tol
-    assert bad.mean() < 0.01, f"{bad.sum()} of {bad.size} observation rows differ by more than {tol}"
+    name = os.path.basename(path)[:-4]
+    out, post = _run_gpu(scenario, cfg, pre_state(g), g["actions"])
+    assert int(out["qp_sweeps"].max()) < 40, "a barrier QP hit its sweep cap: the result would be an unconverged iterate"
+    got = dict(out, poses=post["poses"])
+    for k in parity.MASK_KEYS:
+        got[k] = post[k]
+    m = parity.check_step_parity(scenario, cfg, name, got, parity.golden_want(g), theta_limit=parity.theta_bound(name))
+    rep = parity.load_report()["fixtures"][name]
+    # the kernels are bit-identical to the float32 oracle the report was generated from
+    assert m["tie_rows"] == rep["tie_rows"] and abs(m["max_xy"] - rep["max_xy"]) < 1e-12, (m, rep)
