@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no torchrun around it launches its own N ranks (one process per
+GPU, backend nccl = RCCL; the parent never touches a GPU) and relays rank 0's line.
+
 One "step" = one rg_step launch = one env step (U = 29 sim sub-iterations) of every env of
 the workload: PredatorCapturePrey-v0, 4096 envs x 5 agents per GPU (BASELINE.json configs[1];
 N GPUs = N x 4096 envs, weak scaling), random policy.  Actions are synthetic (uniform ints,
@@ -28,22 +31,28 @@ ALGO_BYTES_OTHER = {"Warehouse": 896, "MaterialTransport": 510}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def measured_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_final_pmc_summary.csv: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc runs).
-    Counters cannot be read from inside an un-profiled run; returns (bytes, source) or (None, None)."""
-    path = os.path.join(ROOT, "profiles", "r1_final_pmc_summary.csv")
-    try:
-        import csv
-        kb = {}
-        for r in csv.DictReader(open(path)):
-            if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and "rg::step_kernel<0, 8, false, 5, false>" in r["kernel"]:
-                kb[r["counter"]] = float(r["mean_per_launch"])
-        if len(kb) == 2:
-            return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, "profiles/r1_final_pmc_summary.csv"
-    except OSError:
-        pass
-    return None, None
+PMC_PROFILE = os.path.join("profiles", "r2_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
+PMC_FALLBACKS = (os.path.join("profiles", "r2a_xcd_pmc_summary.csv"), os.path.join("profiles", "r1_final_pmc_summary.csv"))
+HEADLINE_KERNEL = "rg::step_kernel<0, 8, false, 5, false>"
+SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4     # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2400 MHz, one wave issues a VALU op per 4 cycles
+
+
+def committed_counters():
+    """Per-launch counters of the headline kernel from the COMMITTED rocprofv3 PMC passes of this same command
+    (separate --pmc runs; FETCH_SIZE / WRITE_SIZE in KB).  Counters cannot be read from inside an un-profiled
+    run: these are constants of the committed profile, labelled as such in the line.  Returns (dict, path)."""
+    import csv
+    for rel in (PMC_PROFILE,) + PMC_FALLBACKS:
+        try:
+            vals = {}
+            for r in csv.DictReader(open(os.path.join(ROOT, rel))):
+                if HEADLINE_KERNEL in r["kernel"]:
+                    vals[r["counter"]] = float(r["mean_per_launch"])
+            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                return vals, rel
+        except OSError:
+            continue
+    return {}, None
 
 
 def _port_worker(seconds, seed):
@@ -87,11 +96,26 @@ def _oracle_worker(seconds, seed):
     print(f"PORT_STEPS {n * E} {time.perf_counter() - t0:.3f}")
 
 
-def cpu_all_cores(seconds=8.0, worker="_port_worker"):
-    """the same port, one env per process, one process per host core (the shape of
+def usable_cores():
+    """(cores this job may run on, why): the affinity mask, cut down by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0))
+    why = f"sched_getaffinity ({n} of {os.cpu_count()} host cores)"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            q = max(1, int(float(quota) / float(period) + 0.5))
+            if q < n:
+                n, why = q, f"cgroup cpu.max = {quota}/{period} ({q} of {os.cpu_count()} host cores)"
+    except (OSError, ValueError):
+        pass
+    return n, why
+
+
+def cpu_all_cores(seconds=8.0, worker="_port_worker", n=None):
+    """the same port, one env per process, one process per core (the shape of
     EPyMARL's parallel runner).  CPU-only child processes; returns (agent-steps/s, processes)."""
     import subprocess
-    n = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))   # one GPU's share of the host: 16 cores
+    n = max(1, n or usable_cores()[0])
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.{worker}({seconds}, int(sys.argv[1]))"
     procs = [subprocess.Popen([sys.executable, "-c", code, str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
@@ -155,16 +179,28 @@ def cpu_baseline(seconds_budget=12.0):
     # under rocprofv3 the profiler's preloaded library has already initialised the GPU in this process:
     # no child processes then (each would be an exec after GPU initialisation)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ)
-    all_rate, n_proc = (None, 0) if profiled else cpu_all_cores()
-    c_all, _ = (None, 0) if profiled else cpu_all_cores(4.0, "_oracle_worker")
+    # every core this job may use (affinity mask / cgroup quota -- stated in the line), and the 16-core share of
+    # one GPU of an 8-GPU, 128-core-per-socket host beside it
+    n_all, why = usable_cores()
+    n_all = min(n_all, 256)
+    all_rate, n_proc = (None, 0) if profiled else cpu_all_cores(n=n_all)
+    c_all, _ = (None, 0) if profiled else cpu_all_cores(4.0, "_oracle_worker", n=n_all)
+    share = min(16, n_all)
+    if profiled or share == n_all:
+        share_rate, c_share = all_rate, c_all
+    else:
+        share_rate, _ = cpu_all_cores(n=share)
+        c_share, _ = cpu_all_cores(4.0, "_oracle_worker", n=share)
     return {"value": py_rate, "unit": "agent-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} env-steps of 1 env x 5 agents, NumPy float64 port in the reference's shape "
                       f"(oracle/np_port.py), {dt:.1f} s on one core",
-            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "usable_cores": n_all, "usable_cores_source": why,
             "all_cores": {"value": all_rate, "cores": n_proc, "kind": "port",
-                          "sample": f"{n_proc} processes x 1 env each (EPyMARL parallel-runner shape; one GPU's share of "
-                                    f"the host cores), 8 s" if not profiled else "skipped under rocprofv3 (no child processes)"},
-            "c_oracle_f64_1core": c_rate, "c_oracle_f64_all_cores": {"value": c_all, "cores": n_proc}}
+                          "sample": f"{n_proc} processes x 1 env each (EPyMARL parallel-runner shape) on every core this "
+                                    f"job may use, 8 s" if not profiled else "skipped under rocprofv3 (no child processes)"},
+            "gpu_share_16_cores": {"value": share_rate, "cores": share, "kind": "port"},
+            "c_oracle_f64_1core": c_rate, "c_oracle_f64_all_cores": {"value": c_all, "cores": n_proc},
+            "c_oracle_f64_gpu_share": {"value": c_share, "cores": share}}
 
 
 SATURATED_ENVS = 524288
@@ -229,6 +265,93 @@ def saturated_leg(dev, overrides):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment; one process per GPU, backend nccl unless --dist-backend says otherwise),
+    relay rank 0's JSON line, exit non-zero if any rank fails or the rendezvous does not complete.
+    The parent imports neither torch nor HIP: the children are fresh processes, nothing is exec'ed after a GPU
+    has been initialised."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    argv = [a for a in sys.argv[1:]]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("RG_BENCH_LAUNCH_TIMEOUT", "900"))
+    rc, line = 0, None
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for ln in out0.splitlines():
+            if ln.startswith("{"):
+                line = ln
+        for r, pr in enumerate(procs):
+            code = pr.wait(timeout=max(1.0, deadline - time.time()))
+            if code != 0:
+                print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
+                rc = rc or code
+    except subprocess.TimeoutExpired:
+        print("bench.py: ranks did not finish in time", file=sys.stderr)
+        rc = 4
+    finally:
+        for pr in procs:                        # exactly the processes started above
+            if pr.poll() is None:
+                pr.kill()
+    if rc == 0 and line is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 5
+    if rc == 0:
+        print(line)
+    return rc
+
+
+def dry_run(args, rank, world, collective):
+    """The N > 1 plumbing without a GPU: parameter block broadcast from rank 0, env sharding, the statistics gather
+    and the max-over-ranks timing reduction, on whatever backend the ranks were started with (gloo on a CPU box)."""
+    import torch
+    import torch.distributed as dist
+    from marbler_amd import load_config, make_params
+    from marbler_amd import dist as rgdist
+    from marbler_amd.params import params_to_bytes
+    E = args.envs_per_gpu
+    ov = PCP_OVERRIDES if rank == 0 else {}                      # only rank 0 holds the benchmark's overrides
+    params = make_params(args.scenario, load_config(args.scenario, overrides=ov))
+    if world > 1:
+        params = rgdist.broadcast_params(params, src=0, device="cpu")
+    offset, count = rgdist.shard(world * E, rank, world)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    zeros_f, zeros_i = torch.zeros(count), torch.full((count,), rank, dtype=torch.int32)
+    stats = rgdist.gather_episode_stats(zeros_f, zeros_i, zeros_i.clone(), dst=0)
+    if rank == 0:
+        import hashlib
+        out = {"metric": "env agent-steps/sec", "value": None, "unit": "agent-steps/s", "n_gpus": world, "steps": 0,
+               "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "none (dry run: no GPU work)", "dry_run": True,
+               "config": {"workload": f"{args.scenario}-v0, {E} envs x {params.n_agents} agents per GPU (dry run)",
+                          "envs_per_gpu": E, "agents": int(params.n_agents), "parallelism": f"env-sharded x{world}"},
+               "params_sha1": hashlib.sha1(params_to_bytes(params)).hexdigest(), "shard_of_rank_0": [offset, count],
+               "gathered_envs": int(stats[0].numel()), "gathered_rank_ids": sorted(set(int(v) for v in stats[1]))}
+        if collective is not None:
+            out["collective"] = collective
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,12 +364,22 @@ def main():
     ap.add_argument("--dist-backend", default=None, help="nccl (default, = RCCL) | gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (a 1-GPU box); never for a measured run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: ranks rendezvous, broadcast the parameter block, shard the envs, gather "
+                         "(empty) statistics and print the line with value null -- the N > 1 plumbing on a CPU box")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))            # this process never touches a GPU
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: refusing to report a line "
+              f"for a different number of ranks", file=sys.stderr)
+        sys.exit(2)
 
     # The CPU baseline runs first, while this process has not touched the GPU: it starts child
     # processes (one env each on the host cores), and nothing is exec'ed after HIP is initialised.
     cpu_ref = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu_ref = cpu_baseline()
 
     import torch
@@ -255,9 +388,22 @@ def main():
     from marbler_amd import dist as rgdist
 
     rank, world, local = rgdist.init_from_env(backend=args.dist_backend, device_index=0 if args.share_gpu else None)
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    collective = None
+    if world > 1:
+        # every rank reports in: an all_gather of the rank ids over the backend the run uses
+        cdev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", local)
+        me = torch.tensor([rank], dtype=torch.int64, device=cdev)
+        seen = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(seen, me)
+        ranks_seen = sorted(int(t.item()) for t in seen)
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": ranks_seen,
+                      "library": "RCCL over xGMI (torch.distributed nccl backend on ROCm)" if dist.get_backend() == "nccl"
+                                 else "gloo over TCP loopback (rehearsal)"}
+        if ranks_seen != list(range(args.gpus)):
+            print(f"bench.py: ranks seen {ranks_seen}, expected 0..{args.gpus - 1}", file=sys.stderr)
+            sys.exit(3)
+    if args.dry_run:
+        return dry_run(args, rank, world, collective)
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
     E = args.envs_per_gpu
@@ -330,8 +476,19 @@ def main():
         bytes_per_launch = (ALGO_BYTES_PER_ENV_STEP if args.scenario == "PredatorCapturePrey"
                             else ALGO_BYTES_OTHER[args.scenario]) * E
         achieved = bytes_per_launch / (gpu_ms_total / K * 1e-3) / 1e9 if bytes_per_launch else None
-        traffic, traffic_src = measured_traffic() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU) \
-            else (None, None)
+        counters, counters_src = committed_counters() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU) \
+            else ({}, None)
+        traffic = (counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0 if counters else None
+        kernel_s = gpu_ms_total / K * 1e-3
+        valu = None
+        if "SQ_INSTS_VALU" in counters:
+            insts = counters["SQ_INSTS_VALU"]
+            valu = {"insts_per_launch": insts, "waves_per_launch": counters.get("SQ_WAVES"),
+                    "issue_util": insts * VALU_ISSUE_CYCLES / (kernel_s * CLOCK_HZ * SIMDS),
+                    "formula": "SQ_INSTS_VALU x 4 issue cycles / (kernel time x 2.4 GHz x 1024 SIMDs)",
+                    "kernel_time": "this run (HIP events)", "source": counters_src,
+                    "note": "the binding roof: one wave per SIMD executes a dependent instruction chain "
+                            "(~6 cycles per instruction measured, tools/ubench); launch time = the slowest wave"}
         out = {
             "metric": "env agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
@@ -341,7 +498,8 @@ def main():
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_kind": "from_committed_profile (rocprofv3 --pmc passes of this command; not measured in this run)",
+                         "traffic_source": counters_src, "valu": valu,
                          "kernel": (f"rg::step_kernel<{args.scenario},GW={4 if N <= 4 else 8 if N <= 8 else 16},N={N}> (lane group per env)"
                                     if (args.scenario != "PredatorCapturePrey" or E < 40960)
                                     else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)"),
@@ -352,6 +510,8 @@ def main():
                          "note": "latency/VALU-bound fused step (~120 flop/B): HBM fraction is structurally tiny, "
                                  "see DESIGN.md"},
         }
+        if collective is not None:
+            out["collective"] = collective
         if stats is not None:
             rs, cs, ss = stats
             n_ep = int(cs.sum().item())

@@ -69,26 +69,33 @@ def broadcast_params(params, src=0, device=None):
 
 
 def gather_episode_stats(done_return_sum, done_count, done_steps_sum, dst=0):
-    """Gathers the per-env [E_local] statistics of every rank to `dst` (fixed-size all_gather, as
-    the shards are equal up to one env).  Returns (returns [E_total], counts, steps) on dst,
-    None elsewhere.  With no process group: the inputs."""
+    """Gathers the per-env [E_local] statistics of every rank to `dst`: returns as float32, episode counts and
+    step totals as int64 (exact -- never through a float).  Two fixed-size collectives per call (shards are
+    equal up to one env; shorter shards are padded).  Returns (returns [E_total] f32, counts i64, steps i64) on
+    `dst`, None elsewhere.  With no process group: the inputs.
+    RCCL (nccl backend) has a true gather to one root; gloo on CPU does too."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return done_return_sum, done_count, done_steps_sum
-    world = dist.get_world_size()
+        return done_return_sum, done_count.to(torch.int64), done_steps_sum.to(torch.int64)
+    world, rank = dist.get_world_size(), dist.get_rank()
     cdev = collective_device(done_return_sum.device)
-    done_return_sum, done_count, done_steps_sum = (t.to(cdev) for t in (done_return_sum, done_count, done_steps_sum))
-    n = torch.tensor([done_return_sum.numel()], device=cdev)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    m = int(max(s.item() for s in sizes))
-    packed = torch.zeros(3, m, dtype=torch.float32, device=done_return_sum.device)
     k = done_return_sum.numel()
-    packed[0, :k] = done_return_sum
-    packed[1, :k] = done_count.float()
-    packed[2, :k] = done_steps_sum.float()
-    out = [torch.zeros_like(packed) for _ in range(world)]
-    dist.all_gather(out, packed)
-    if dist.get_rank() != dst:
+    n = torch.tensor([k], dtype=torch.int64, device=cdev)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)                     # 8 bytes per rank; every rank needs the padded size
+    sizes = [int(x.item()) for x in sizes]
+    m = max(sizes)
+    f = torch.zeros(m, dtype=torch.float32, device=cdev)
+    f[:k] = done_return_sum.to(cdev)
+    i = torch.zeros(2, m, dtype=torch.int64, device=cdev)
+    i[0, :k] = done_count.to(cdev)
+    i[1, :k] = done_steps_sum.to(cdev)
+    fl = [torch.zeros_like(f) for _ in range(world)] if rank == dst else None
+    il = [torch.zeros_like(i) for _ in range(world)] if rank == dst else None
+    dist.gather(f, fl, dst=dst)
+    dist.gather(i, il, dst=dst)
+    if rank != dst:
         return None
-    cat = torch.cat([o[:, :int(s.item())] for o, s in zip(out, sizes)], dim=1)
-    return cat[0], cat[1].to(torch.int64), cat[2].to(torch.int64)
+    ret = torch.cat([t[:c] for t, c in zip(fl, sizes)])
+    cnt = torch.cat([t[0, :c] for t, c in zip(il, sizes)])
+    stp = torch.cat([t[1, :c] for t, c in zip(il, sizes)])
+    return ret, cnt, stp

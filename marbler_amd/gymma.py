@@ -72,7 +72,9 @@ class GymmaVecEnv(object):
         self._obs = torch.where(ended[:, None, None], torch.zeros_like(obs), obs)
         self._terminal_obs = obs.clone() if self._can_truncate else obs
         if self._can_truncate:
-            self.env.reset(truncated)   # masked launch, no host round trip (waves without a flagged env exit at once)
+            # masked launch, no host round trip (waves without a flagged env exit at once); the truncated episodes
+            # are booked into the episode statistics like the ones the scenario ended
+            self.env.reset(truncated, book_episode=True)
         self._elapsed.masked_fill_(ended, 0)
         out = dict(info)
         out["TimeLimit.truncated"] = truncated
@@ -129,7 +131,7 @@ class GymmaVecEnv(object):
 class GymmaEnv(object):
     """One env with EPyMARL's Python-level types (lists of numpy arrays, floats, bools)."""
 
-    def __init__(self, key, time_limit, pretrained_wrapper=None, seed=0, device="cuda:0", **kwargs):
+    def __init__(self, key, time_limit, pretrained_wrapper=None, seed=None, device="cuda:0", **kwargs):
         self._v = GymmaVecEnv(key, 1, time_limit, device=device, seed=seed, overrides=kwargs or None)
         # auto-reset is the runner's job in EPyMARL: keep the terminal state until reset() is called
         self._v.env.auto_reset = False
@@ -148,7 +150,8 @@ class GymmaEnv(object):
             out["TimeLimit.truncated"] = True
         if viol:
             from .vec_env import VIOLATION_MESSAGES
-            out["message"] = VIOLATION_MESSAGES[viol]
+            # simple.py:176 files the violation string under 'remaining'
+            out["remaining" if self._v.scenario == "Simple" else "message"] = VIOLATION_MESSAGES[viol]
         return float(reward.sum()), done or truncated, out
 
     def reset(self):

@@ -26,6 +26,8 @@ class VecRobotariumEnv(object):
         """scenario: 'PredatorCapturePrey' | 'Warehouse' | 'MaterialTransport' | 'Simple' | 'ArcticTransport'
         (wrapper.py:12-16).
         config_path / overrides: the reference's scenario YAML (same keys) and a dict of overrides.
+        seed: key of the device reset sampler (one Philox stream per (global env, episode)); None draws one
+            from os.urandom, the reference's `seed: -1` = "do not seed" (PredatorCapturePrey.py:27-28).
         env_offset: global index of env 0 of this shard (RNG streams are keyed by global index).
         auto_reset: finished envs are reset inside the step launch.
         reference_reset_obs: reset() returns zeros like the reference (PredatorCapturePrey.py:136);
@@ -47,6 +49,9 @@ class VecRobotariumEnv(object):
         self.N = int(params.n_agents)
         self.D = int(params.obs_dim)
         self.P = int(params.num_prey)
+        if seed is None:
+            import os
+            seed = int.from_bytes(os.urandom(8), "little")
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.env_offset = int(env_offset)
         self.auto_reset = bool(auto_reset)
@@ -99,9 +104,12 @@ class VecRobotariumEnv(object):
         self.violation = view("violation", E, u8, (E,))
         self.qp_sweeps = torch.zeros(E, dtype=i32, device=dev) if collect_qp_stats else None
 
+        if dev.index is None:
+            self.device = dev = torch.device("cuda", torch.cuda.current_device())
         self._stream = torch.cuda.current_stream(dev)
-        self._h = self.lib.rg_create(C.byref(params), self.E, self.env_offset, dev.index or 0,
-                                     C.c_void_p(self._stream.cuda_stream))
+        self._stream_ptr = self._stream.cuda_stream
+        self._h = self.lib.rg_create(C.byref(params), self.E, self.env_offset, dev.index,
+                                     C.c_void_p(self._stream_ptr))
         if not self._h:
             raise _lib.RobogymError("rg_create failed: " + self.lib.rg_last_error().decode())
         st = _lib.RgState(*(t.data_ptr() for t in (
@@ -126,14 +134,32 @@ class VecRobotariumEnv(object):
     def num_envs(self):
         return self.E
 
-    def reset(self, mask=None):
+    def _sync_stream(self):
+        """Launches go to torch's CURRENT stream of the env's device (so they are ordered with the torch ops
+        around them, also under `with torch.cuda.stream(s)`); the C side selects the device itself."""
+        ptr = torch.cuda.current_stream(self.device).cuda_stream
+        if ptr != self._stream_ptr:
+            _lib.check(self.lib.rg_set_stream(self._h, C.c_void_p(ptr)), "rg_set_stream")
+            self._stream_ptr = ptr
+
+    def reset(self, mask=None, book_episode=False, reference_rng=None, py_random=None):
         """scenario.reset() for all envs (mask=None) or those with mask != 0.  Returns obs [E,N,D]:
-        zeros where the reference would (reference_reset_obs), else the fresh observation."""
+        zeros where the reference would (reference_reset_obs), else the fresh observation.
+        The running episode return of a reset env restarts at zero; book_episode=True first counts the
+        abandoned episode in done_return_sum / done_count / done_steps_sum (an episode cut short by a
+        time limit outside the scenario, e.g. gym's TimeLimit).
+        reference_rng: parity mode (row a17) -- a seeded `np.random.RandomState` (or the `np.random` module)
+        from which the initial conditions are drawn on the host exactly as the reference draws them
+        (marbler_amd/reference_reset.py), env by env in index order, and uploaded; the device sampler's
+        Philox streams stay the throughput path."""
+        self._sync_stream()
         mptr = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mptr = mask.data_ptr()
-        _lib.check(self.lib.rg_reset(self._h, mptr, self.seed), "rg_reset")
+        _lib.check(self.lib.rg_reset(self._h, mptr, self.seed, _lib.RESET_BOOK_EPISODE if book_episode else 0), "rg_reset")
+        if reference_rng is not None:
+            self._upload_reference_reset(mask, reference_rng, py_random)
         if self.reference_reset_obs:
             if mask is None:
                 self.obs.zero_()
@@ -142,10 +168,35 @@ class VecRobotariumEnv(object):
             return self.obs
         return self.get_obs()
 
+    def _upload_reference_reset(self, mask, rng, py_random):
+        import numpy as np
+        from .reference_reset import draw_reset
+        if self.cfg is None:
+            raise ValueError("reference_rng needs the scenario config (construct the env from a config, not from params)")
+        idx = list(range(self.E)) if mask is None else [int(i) for i in torch.nonzero(mask).flatten().cpu()]
+        if not idx:
+            return
+        draws = [draw_reset(self.scenario, self.cfg, rng, py_random) for _ in idx]
+        ix = torch.as_tensor(idx, device=self.device)
+
+        def put(dst, key, dtype):
+            arr = np.stack([np.asarray(d[key]) for d in draws]).astype(dtype)
+            dst[ix] = torch.as_tensor(arr, device=self.device).reshape((len(idx),) + tuple(dst.shape[1:]))
+
+        put(self.poses, "poses", np.float32)
+        if "prey_loc" in draws[0]:
+            put(self.prey_loc, "prey_loc", np.float32)
+        if "zone_load" in draws[0]:
+            put(self.zone_load, "zone_load", np.int32)
+        if "grid" in draws[0]:
+            put(self.grid, "grid", np.uint8)
+            self.goal_col[ix] = torch.as_tensor([d["goal_col"] for d in draws], dtype=torch.int32, device=self.device)
+
     def step(self, actions):
         """actions: int tensor [E,N] on the device (int32 is used as is; other int dtypes are
         converted).  Returns (obs, reward, done, info) as views of the env's output buffers --
         they are overwritten by the next step."""
+        self._sync_stream()
         if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
             self._actions_i32.copy_(actions.reshape(self.E, self.N))
             actions = self._actions_i32
@@ -190,7 +241,8 @@ class VecRobotariumEnv(object):
 
     def step_raw(self, actions_ptr):
         """Hot-loop entry: one rg_step on a pre-validated device pointer to int32 [E,N]; results are
-        in self.obs / reward / done_u8 / dist_travelled / violation / remaining."""
+        in self.obs / reward / done_u8 / dist_travelled / violation / remaining.  Launches on the stream of
+        the last step() / reset() / set_stream() call (no per-call stream lookup)."""
         return self.lib.rg_step(self._h, actions_ptr, self._io_ref, 1 if self.auto_reset else 0, self.seed)
 
     def set_stream(self, stream=None):
@@ -199,6 +251,7 @@ class VecRobotariumEnv(object):
         stream = torch.cuda.current_stream(self.device) if stream is None else stream
         _lib.check(self.lib.rg_set_stream(self._h, C.c_void_p(stream.cuda_stream)), "rg_set_stream")
         self._stream = stream
+        self._stream_ptr = stream.cuda_stream
 
     def rollout(self, actions, out=None):
         """K env steps in one launch for an action sequence known up front (random-policy rollouts,
@@ -209,6 +262,7 @@ class VecRobotariumEnv(object):
         reuse its buffers.  The single-step buffers (self.obs, ...) are left untouched."""
         if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        self._sync_stream()
         K = int(actions.shape[0])
         if tuple(actions.shape) != (K, self.E, self.N):
             raise ValueError(f"actions must be [K,{self.E},{self.N}], got {tuple(actions.shape)}")
@@ -234,19 +288,29 @@ class VecRobotariumEnv(object):
 
     def get_obs(self, out=None):
         """Observation of the current state without stepping (gymma's get_obs())."""
+        self._sync_stream()
         out = self.obs if out is None else out
         _lib.check(self.lib.rg_get_obs(self._h, out.data_ptr()), "rg_get_obs")
         return out
 
     # ------------------------------------------------------------------ state access (parity / checkpoints)
+    # everything a later step depends on: the scenario state, the RNG stream position (reset_count) and the
+    # rollout-statistics accumulators -- a restored snapshot continues bit-identically, statistics included
     STATE_KEYS = ("poses", "carry_dist", "episode_steps", "reset_count", "prey_loc", "prey_sensed", "prey_captured",
-                  "loaded", "load", "zone_load", "messages", "grid", "goal_col", "pixel_type", "reached_goal")
+                  "loaded", "load", "zone_load", "messages", "grid", "goal_col", "pixel_type", "reached_goal",
+                  "ep_return", "done_return_sum", "done_count", "done_steps_sum")
 
     def state_dict(self):
-        return {k: getattr(self, k).clone() for k in self.STATE_KEYS}
+        """Snapshot of the env state (cloned tensors) + the sampler key, loadable with load_state_dict()."""
+        sd = {k: getattr(self, k).clone() for k in self.STATE_KEYS}
+        sd["seed"] = torch.tensor([self.seed & 0xFFFFFFFF, self.seed >> 32], dtype=torch.int64)
+        return sd
 
     def load_state_dict(self, sd):
         for k, v in sd.items():
+            if k == "seed":
+                self.seed = int(v[0]) | (int(v[1]) << 32)
+                continue
             getattr(self, k).copy_(torch.as_tensor(v).to(getattr(self, k).dtype).reshape(getattr(self, k).shape))
 
     def episode_stats(self):

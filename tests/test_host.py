@@ -150,6 +150,9 @@ def test_spaces_match_the_reference_constructors():
         assert float(np.min(o[0].low)) == lo and float(np.max(o[0].high)) == hi
 
 
+BIG = (1 << 24) + 1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -171,7 +174,7 @@ def _worker(rank, world, port, q):
     p = rgdist.broadcast_params(p, src=0, device="cpu")
     off, cnt = rgdist.shard(9, r, w)                               # 9 envs over 2 ranks: 5 + 4
     rs = torch.arange(off, off + cnt, dtype=torch.float32) * 0.5
-    cs = torch.arange(off, off + cnt, dtype=torch.int32)
+    cs = torch.arange(off, off + cnt, dtype=torch.int32) + BIG     # above 2^24: a float32 round trip would lose the low bits
     ss = cs * 10
     out = rgdist.gather_episode_stats(rs, cs, ss, dst=0)
     q.put((r, params_to_bytes(p), None if out is None else [t.tolist() for t in out]))
@@ -198,4 +201,44 @@ def test_broadcast_and_gather_world_size_2_gloo():
     assert res[0][1] == want and res[1][1] == want                 # rank 1 received rank 0's block
     assert res[1][2] is None
     rs, cs, ss = res[0][2]
-    assert rs == [0.5 * i for i in range(9)] and cs == list(range(9)) and ss == [10 * i for i in range(9)]
+    assert rs == [0.5 * i for i in range(9)]
+    assert cs == [BIG + i for i in range(9)] and ss == [10 * (BIG + i) for i in range(9)]     # integers gathered as int64
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_bench_launches_its_own_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` without torchrun starts two ranks itself, rendezvous over 127.0.0.1, broadcasts
+    rank 0's parameter block, shards the envs, gathers the statistics and prints ONE line with n_gpus 2 (the
+    no-GPU dry mode of the N > 1 path; on a GPU node the same launcher runs nccl = RCCL)."""
+    import hashlib
+    import json
+    from marbler_amd import load_config, make_params
+    from marbler_amd.params import params_to_bytes
+    r = _run_bench("--gpus", "2", "--dist-backend", "gloo", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True and d["value"] is None
+    assert d["collective"] == {"backend": "gloo", "world_size": 2, "ranks_seen": [0, 1],
+                               "library": "gloo over TCP loopback (rehearsal)"}
+    assert d["gathered_envs"] == 2 * 4096 and d["gathered_rank_ids"] == [0, 1] and d["shard_of_rank_0"] == [0, 4096]
+    # rank 1 built its block WITHOUT the benchmark's overrides: equality proves the broadcast delivered rank 0's
+    want = make_params("PredatorCapturePrey", load_config("PredatorCapturePrey", overrides={"predator": 3, "capture": 2, "n_agents": 5}))
+    assert d["params_sha1"] == hashlib.sha1(params_to_bytes(want)).hexdigest() and d["config"]["agents"] == 5
+
+
+def test_bench_refuses_a_rank_count_it_was_not_started_with():
+    r = _run_bench("--gpus", "8", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
