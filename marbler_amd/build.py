@@ -65,5 +65,25 @@ def build(force=False, verbose=False, defines=(), out=None):
     return out
 
 
+def build_host_sanitized(out=None):
+    """CPU sanitizer tier: the C ABI's host half (csrc/robogym_capi.hip) compiled for the HOST ONLY with
+    ASan + UBSan, linked against tests/sanitize/launch_stubs.cpp in place of the device translation units.
+    Used by tests/test_sanitizers.py for the no-GPU cases of tests/test_host.py; never shipped.  (GPU ASan is
+    not available on this pool: sanitizers run on the CPU build only.)"""
+    out = out or os.path.join(HERE, "build", "librobogym_capi_asan.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    stubs = os.path.join(HERE, "..", "tests", "sanitize", "launch_stubs.cpp")
+    cmd = [hipcc_path(), "-x", "hip", "--offload-host-only", "-O1", "-g", "-fno-omit-frame-pointer",
+           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fPIC", "-shared", "-std=c++17",
+           "-I", CSRC, os.path.join(CSRC, "robogym_capi.hip"), stubs, "-o", out]
+    subprocess.check_call(cmd)
+    return out
+
+
+def asan_runtime():
+    """clang's shared ASan runtime (to LD_PRELOAD into the python process that loads the sanitized library)."""
+    return subprocess.check_output([hipcc_path(), "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

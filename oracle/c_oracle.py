@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_OVERRIDE = os.environ.get("ORACLE_LIB")   # e.g. the ASan + UBSan build (`make -C oracle asan`, tests/test_sanitizers.py)
 MAXN, MAXP = 16, 64
 SCN = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2, "Simple": 3, "ArcticTransport": 4}
 
@@ -60,7 +61,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build_library())
+        _lib = C.CDLL(_OVERRIDE) if _OVERRIDE else C.CDLL(build_library())
         assert _lib.orc_sizeof_params() == C.sizeof(OrcParams), "orc_params layout mismatch"
     return _lib
 
