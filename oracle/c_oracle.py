@@ -77,7 +77,7 @@ def params_from_config(scenario, cfg, collision_variant="offset", dtype=np.float
     p.qp_max_sweeps = cfg.get("qp_max_sweeps", QP_MAX_SWEEPS[np.dtype(dtype).name])
     p.scenario = SCN[scenario]
     p.update_frequency = int(cfg["update_frequency"])
-    p.controller_period = 15
+    p.controller_period = 1 if cfg.get("robotarium", False) else 15   # roboEnv.py:63
     p.max_episode_steps = int(cfg["max_episode_steps"])
     p.penalize_violations = int(bool(cfg["penalize_violations"]))
     bc = cfg.get("barrier_certificate", "safe")   # roboEnv.py:15-18: absent -> Controller() -> 'safe'

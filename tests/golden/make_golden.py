@@ -152,6 +152,9 @@ CASES = [
     ("simple_n6_random", "Simple", {"n_agents": 6}, [105], 110, 1.0),
     ("arctic_default", "ArcticTransport", {}, [111, 112, 113], 130, 0.25),
     ("arctic_random", "ArcticTransport", {}, [115], 130, 1.0),
+    # `robotarium: True`: the controller (and its QP) on every sub-iteration (roboEnv.py:63)
+    ("pcp_n5_robotarium", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "robotarium": True}, [121], 90, 0.35),
+    ("mt_n4_robotarium", "MaterialTransport", {"robotarium": True}, [123], 40, 0.3),
 ]
 
 
@@ -231,7 +234,10 @@ def pack(recs):
 def main():
     assert rh.reference_available(), "run in the build container (needs /root/reference)"
     import json
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]      # python make_golden.py [fixture names]: just those
     for name, scenario, ov, seeds, steps, eps in CASES:
+        if only and name not in only:
+            continue
         recs, first, cfg = run_case(name, scenario, ov, seeds, steps, eps)
         d = pack(recs)
         d["first_after_reset"] = first
@@ -244,7 +250,7 @@ def main():
         v = d["viol"]
         print(f"{name}: T={len(recs)} done={int(d['done'].sum())} viol={int((v > 0).sum())} "
               f"reward_sum={d['reward'][:, 0].sum():.3f}")
-    for name, scenario, cfg, recs in forced_violation_cases():
+    for name, scenario, cfg, recs in ([] if only else forced_violation_cases()):
         d = pack(recs)
         d["first_after_reset"] = np.array([1] + [0] * (len(recs) - 1), dtype=np.uint8)
         d["config_json"] = np.array(json.dumps(cfg))

@@ -118,8 +118,10 @@ def test_params_follow_the_reference_configs():
     with pytest.raises(ValueError, match="grid cells"):           # 6 agents on the default 1x6 grid (Appendix C)
         make_params("MaterialTransport", load_config("MaterialTransport", overrides={
             "n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3}))
+    assert make_params("Warehouse", load_config("Warehouse")).controller_period == 15          # roboEnv.py:63
+    assert make_params("Warehouse", load_config("Warehouse", overrides={"robotarium": True})).controller_period == 1
     with pytest.raises(ValueError):
-        make_params("Warehouse", load_config("Warehouse", overrides={"robotarium": True}))
+        make_params("Warehouse", load_config("Warehouse", overrides={"real_time": True}))
     with pytest.raises(KeyError):
         make_params("ArcticTransport", {})
 
