@@ -172,64 +172,72 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
 // ------------------------------------------------------------------ neighbour observations
 // K nearest neighbours' own-observation rows (staged in LDS) into obs slots 1..K: ascending
 // squared distance, ties -> lower index (the canonical order for misc.py:20-25); K >= N-1: all
-// others in index order.
-template <int GW, int OD>
+// others in index order.  Partner rows come from LDS by address, so -- unlike the DPP rounds of the
+// controller -- the partners need not be the XOR partners: agent a visits (a + r) mod N, r = 1..N-1.
+// With the agent count a compile-time constant (NT) that is N-1 slots and (N-1)(N-2)/2 comparisons
+// instead of GW-1 and (GW-1)(GW-2)/2 (N = 5 in groups of 8: 4 and 6 instead of 7 and 21).
+template <int GW, int OD, int NT>
 __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb, int ag, int gbase, bool lane_ok,
                                                     float x, float y, float *obs_row) {
+    constexpr int M = NT > 0 ? NT - 1 : GW - 1;  // partner slots
     // 64-bit sort keys: (bits of the squared distance, partner index) -- non-negative floats order
     // like their bit patterns, so one unsigned 64-bit compare is the (distance, index) lexicographic
     // test.  Absent partners get keys above every real one.
-    unsigned long long key[GW - 1];
-    bool ok[GW - 1];
-    int rank[GW - 1];
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        const float2 pxy = *reinterpret_cast<const float2 *>(&lds.own[gbase + (ag ^ K)][0]);  // partner's (x, y)
+    unsigned long long key[M > 0 ? M : 1];
+    bool ok[M > 0 ? M : 1];
+    int rank[M > 0 ? M : 1], who[M > 0 ? M : 1];
+    static_for<0, M>([&](auto RR) {
+        constexpr int r = decltype(RR)::value;
+        int j = ag + r + 1;
+        j = j >= N ? j - N : j;
+        j = j & (GW - 1);  // idle lanes (ag >= N) stay inside the group's rows
+        who[r] = j;
+        const float2 pxy = *reinterpret_cast<const float2 *>(&lds.own[gbase + j][0]);  // partner's (x, y)
         const float dx = pxy.x - x, dy = pxy.y - y;
         const float d2 = dx * dx + dy * dy;
-        ok[K - 1] = lane_ok & ((ag ^ K) < N);
-        const unsigned int hi = ok[K - 1] ? __builtin_bit_cast(unsigned int, d2) : 0xFFFFFFFFu;
-        key[K - 1] = (static_cast<unsigned long long>(hi) << 32) | static_cast<unsigned int>(ag ^ K);
-        rank[K - 1] = GW - 1 - K;  // pairs in which this round is the first element; each lost comparison adds one below
+        ok[r] = lane_ok & (r + 1 < N);
+        const unsigned int hi = ok[r] ? __builtin_bit_cast(unsigned int, d2) : 0xFFFFFFFFu;
+        key[r] = (static_cast<unsigned long long>(hi) << 32) | static_cast<unsigned int>(j);
+        rank[r] = M - 1 - r;  // pairs in which this slot is the first element; each lost comparison adds one below
     });
     const bool all_others = Knb >= N - 1;
-    // rank of partner K = number of partners ahead of it: one comparison per unordered pair (Q < K)
-    static_for<2, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        static_for<1, K>([&](auto QQ) {
-            constexpr int Q = decltype(QQ)::value;
-            const int q_first = key[Q - 1] < key[K - 1] ? 1 : 0;
-            rank[K - 1] += q_first;
-            rank[Q - 1] -= q_first;
+    // rank of a partner = number of partners ahead of it: one comparison per unordered pair (q < k)
+    static_for<1, M>([&](auto KK) {
+        constexpr int k = decltype(KK)::value;
+        static_for<0, k>([&](auto QQ) {
+            constexpr int q = decltype(QQ)::value;
+            const int q_first = key[q] < key[k] ? 1 : 0;
+            rank[k] += q_first;
+            rank[q] -= q_first;
         });
     });
     // the rows first (independent LDS reads in flight together), then the predicated stores
-    float row[GW - 1][OD];
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        const float *src = &lds.own[gbase + (ag ^ K)][0];
+    float row[M > 0 ? M : 1][OD];
+    static_for<0, M>([&](auto RR) {
+        constexpr int r = decltype(RR)::value;
+        const float *src = &lds.own[gbase + who[r]][0];
         if constexpr (OD == 4) {
             const float4 v = *reinterpret_cast<const float4 *>(src);
-            row[K - 1][0] = v.x;
-            row[K - 1][1] = v.y;
-            row[K - 1][2] = v.z;
-            row[K - 1][3] = v.w;
+            row[r][0] = v.x;
+            row[r][1] = v.y;
+            row[r][2] = v.z;
+            row[r][3] = v.w;
         } else {
 #pragma unroll
-            for (int c = 0; c < OD; ++c) row[K - 1][c] = src[c];
+            for (int c = 0; c < OD; ++c) row[r][c] = src[c];
         }
     });
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        const int j = ag ^ K;
-        const int slot = all_others ? (j < ag ? j : j - 1) : rank[K - 1];
-        if (ok[K - 1] & (all_others | (slot < Knb))) {
+    static_for<0, M>([&](auto RR) {
+        constexpr int r = decltype(RR)::value;
+        const int j = who[r];
+        const int slot = all_others ? (j < ag ? j : j - 1) : rank[r];
+        if (ok[r] & (all_others | (slot < Knb))) {
             float *o = obs_row + (slot + 1) * OD;
             if constexpr (OD == 4) {
-                *reinterpret_cast<float4 *>(o) = make_float4(row[K - 1][0], row[K - 1][1], row[K - 1][2], row[K - 1][3]);
+                *reinterpret_cast<float4 *>(o) = make_float4(row[r][0], row[r][1], row[r][2], row[r][3]);
             } else {
 #pragma unroll
-                for (int c = 0; c < OD; ++c) o[c] = row[K - 1][c];
+                for (int c = 0; c < OD; ++c) o[c] = row[r][c];
             }
         }
     });
@@ -712,10 +720,10 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 #pragma unroll
                 for (int cc = 0; cc < 6; ++cc) obs_row[cc] = lds.own[lane][cc];
             }
-            write_neighbour_obs<GW, 6>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
+            write_neighbour_obs<GW, 6, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         } else {
             if (lane_ok) *reinterpret_cast<float4 *>(obs_row) = make_float4(x, y, qx, qy);
-            write_neighbour_obs<GW, 4>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
+            write_neighbour_obs<GW, 4, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         }
         RG_STAMP_E(1);  // observations written
         if constexpr (!OBS_ONLY) {  // a14 reward / termination (PredatorCapturePrey.py:155-176, 209-216)
@@ -747,7 +755,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             obs_row[1] = y;
             obs_row[2] = loaded ? 1.0f : 0.0f;
         }
-        write_neighbour_obs<GW, 3>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
+        write_neighbour_obs<GW, 3, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         if constexpr (!OBS_ONLY) {
             if (viol) {
                 reward = p.violation_reward;
@@ -779,7 +787,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             obs_row[2 * N] = goal_x;
             obs_row[2 * N + 1] = goal_y;
         }
-        write_neighbour_obs<GW, 2>(lds, N, N - 1, ag, gbase, lane_ok, x, y, obs_row);  // all others, index order
+        write_neighbour_obs<GW, 2, NT>(lds, N, N - 1, ag, gbase, lane_ok, x, y, obs_row);  // all others, index order
         if constexpr (!OBS_ONLY) {
             if (viol) {
                 reward = p.violation_reward;

@@ -138,3 +138,33 @@ def test_batched_runner_collects_transitions():
     # a second call continues the same episodes
     b2 = runner.run(10)
     assert torch.equal(b2["episode_start"][0], b["terminated"][-1])
+
+
+@pytest.mark.parametrize("name", ["pcp_n5", "warehouse_n8", "mt_n6", "viol_PredatorCapturePrey_collision"])
+def test_gymma_env_reduces_the_reference_vectors_like_epymarl(name):
+    """GymmaEnv (EPyMARL's gymma contract: float(sum(reward_n)), all(done_n), padded per-agent observations,
+    state = their concatenation) fed the reference's own states and actions must return the reductions of the
+    reference's own outputs (tests/golden, captured from the reference Wrapper)."""
+    import torch
+    import parity
+    from marbler_amd.gymma import GymmaEnv
+    g, scenario, cfg = load_golden(os.path.join(GOLDEN_DIR, name + ".npz"))
+    env = GymmaEnv(f"robotarium_gym:{scenario}-v0", time_limit=10 ** 6, seed=1, **{k: v for k, v in cfg.items() if k not in ("seed", "device")})   # the YAML's `device` is the torch device of the reference's actor
+    env.reset()
+    st = pre_state(g)
+    N, D = env.n_agents, env.get_obs_size()
+    assert env.get_env_info()["state_shape"] == N * D and g["obs"].shape[1:] == (N, D)
+    for t in list(range(min(40, len(g["actions"])))) + [int(i) for i in np.nonzero(g["done"])[0][:3]]:
+        env._v.env.load_state_dict({GPU_NAME.get(k, k): torch.as_tensor(np.asarray(v[t:t + 1])) for k, v in st.items()})
+        r, done, info = env.step([int(a) for a in g["actions"][t]])
+        assert isinstance(r, float) and abs(r - float(np.sum(g["reward"][t]))) <= 1e-4
+        assert done == bool(g["done"][t])
+        obs = np.stack(env.get_obs())
+        for a in np.nonzero(np.abs(obs - g["obs"][t]).max(axis=1) > parity.TOL)[0]:
+            why, _ = parity.explain_row(scenario, cfg, int(a), obs.astype(np.float64), g["obs"][t], g["post_poses"][t],
+                                        g["post_prey_loc"][t] if "post_prey_loc" in g.files else None,
+                                        g["post_prey_captured"][t] if "post_prey_captured" in g.files else None)
+            assert why is None, (t, int(a), why)
+        assert np.array_equal(env.get_state(), obs.reshape(-1))
+        assert info.get("message") == MSG[int(g["viol"][t])]
+    env.close()

@@ -104,6 +104,12 @@ if __name__ == "__main__":
                     us = a.elapsed_time(b) * 1e3 / (reps * K)
                     print(json.dumps({"kernel": kern, "E": E, "K": K, "us_per_step": us,
                                       "agent_steps_per_s": E * 5 / (us * 1e-6)}), flush=True)
+    if args.set == "tpecap":   # thread-per-env kernel at a chip-filling batch: what the QP tail, replays and resets cost
+        os.environ["RG_STEP_KERNEL"] = "tpe"
+        for over, ar in (({}, True), ({"qp_max_sweeps": 4}, True), ({"qp_max_sweeps": 2}, True), ({"qp_max_sweeps": 1}, True),
+                         ({"penalize_violations": False}, True), ({}, False)):
+            r = probe("PredatorCapturePrey", 524288, steps=40, warm=40, auto_reset=ar, **over)
+            print(json.dumps(r), flush=True)
     if args.set == "big":     # one saturated configuration (for rocprofv3 --pmc runs); RG_STEP_KERNEL picks the kernel
         out.append(probe("PredatorCapturePrey", 524288, steps=20, warm=10))
     for r in out:
