@@ -23,11 +23,11 @@ constexpr int MAX_DRAWS = 128;  // u32 draws per reset: 4 + 2N + P <= 4 + 32 + 6
 // land on different L2s: every shared line is fetched by two XCDs and written back as two partial lines.
 // Instead XCD x works through ONE contiguous run of chunks, so shared lines meet in one L2 (measured with
 // rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/).  Affinity only: results do not depend on the block -> XCD map.
-__device__ __forceinline__ int xcd_chunk() {
+__device__ __forceinline__ int xcd_chunk(int G = gridDim.x) {
 #ifdef RG_NO_XCD_REMAP  // diagnostic builds (A/B traffic measurements)
     return blockIdx.x;
 #endif
-    const int b = blockIdx.x, G = gridDim.x;
+    const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int q = G >> 3, r = G & 7;
     return xcd * q + (xcd < r ? xcd : r) + j;
@@ -236,8 +236,11 @@ __device__ __forceinline__ void cell_xy(const rg_grid &grid, int cell, float &x,
     y = (fy + grid.oy1) + grid.oy2;
 }
 
+// episode_pre >= 0: the env's reset_count, already fetched by the caller (the step kernels prefetch it with the rest of
+// the state, so a finished env's reset does not start with a memory round trip of its own)
 template <int SCN, int GW>
-__device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, int e, int g, int ag, bool do_reset) {
+__device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, int e, int g, int ag, bool do_reset,
+                                            int episode_pre = -1) {
     const rg_scenario_params &p = a.p;
     const int N = p.n_agents;
     if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
@@ -247,7 +250,7 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
         constexpr int CELLS = RG_ARCTIC_ROWS * RG_ARCTIC_COLS;
         int32_t episode = 0;
         if (do_reset) {
-            episode = a.st.reset_count[e];
+            episode = episode_pre >= 0 ? episode_pre : a.st.reset_count[e];
             const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
             for (int b = ag; 4 * b < CELLS + 1; b += GW) {
                 uint32_t blk[4];
@@ -291,7 +294,7 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
     const int ndraws = ZD + 2 * N + P;
     int32_t episode = 0;
     if (do_reset) {
-        episode = a.st.reset_count[e];
+        episode = episode_pre >= 0 ? episode_pre : a.st.reset_count[e];
         const uint64_t ge = static_cast<uint64_t>(a.env_offset + e);
         for (int b = ag; 4 * b < ndraws; b += GW) {
             uint32_t blk[4];

@@ -271,57 +271,83 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 #endif
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
-    const int N = NT > 0 ? NT : p.n_agents;
+    // ---- kernel arguments first: every pointer and scalar the loads below need, fetched TOGETHER.  Left to itself
+    // the compiler fetches each kernarg field where it is first used: five dependent scalar-memory round trips, the
+    // state loads issued in between and waited for one group at a time -- 3.3 k of a wave's 24 k cycles went by
+    // before the first controller (tools/stamp_probe.py).  The empty asm makes all of them live here: one trip.
+    const float *q_poses = a.st.poses, *q_carry = a.st.carry_dist, *q_ret = a.st.ep_return, *q_sum = a.st.done_return_sum;
+    const int32_t *q_steps = a.st.episode_steps, *q_act = sv.actions, *q_cnt = a.st.done_count, *q_stp = a.st.done_steps_sum;
+    const int32_t *q_rc = a.st.reset_count;
+    const int q_E = a.E, q_epw = a.envs_per_wave, q_P = p.num_prey, q_N = p.n_agents, q_G = gridDim.x;
+    asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp),
+                 "s"(q_E), "s"(q_epw), "s"(q_P), "s"(q_N), "s"(q_G), "s"(q_rc));
+    const float *q_prey = a.st.prey_loc;
+    const uint8_t *q_sen = a.st.prey_sensed, *q_cap = a.st.prey_captured, *q_loaded = a.st.loaded, *q_grid = a.st.grid;
+    const uint8_t *q_pix = a.st.pixel_type, *q_reached = a.st.reached_goal;
+    const int32_t *q_gcol = a.st.goal_col, *q_msg = a.st.messages, *q_zone = a.st.zone_load, *q_load = a.st.load;
+    if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) asm volatile("" ::"s"(q_prey), "s"(q_sen), "s"(q_cap));
+    else if constexpr (SCN == RG_SCN_WAREHOUSE) asm volatile("" ::"s"(q_loaded));
+    else if constexpr (SCN == RG_SCN_SIMPLE) asm volatile("" ::"s"(q_prey));
+    else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) asm volatile("" ::"s"(q_grid), "s"(q_pix), "s"(q_reached), "s"(q_gcol));
+    else asm volatile("" ::"s"(q_msg), "s"(q_zone), "s"(q_load));
+
+    const int N = NT > 0 ? NT : q_N;
     const int lane = threadIdx.x;
     const int ag = lane & (GW - 1);
     const int g = lane / GW;
     const int gbase = lane & ~(GW - 1);
-    const int epw = a.envs_per_wave > 0 ? a.envs_per_wave : EPW;
-    const int chunk = xcd_chunk();
+    const int epw = q_epw > 0 ? q_epw : EPW;
+    const int chunk = xcd_chunk(q_G);
     const int e = chunk * epw + g;
-    const bool env_ok = (g < epw) & (e < a.E);
+    const bool env_ok = (g < epw) & (e < q_E);
     const bool lane_ok = env_ok && ag < N;
     const size_t eN = static_cast<size_t>(e) * N;
 
-    // ---- loads, all issued up front (coalesced: a wave covers EPW consecutive envs = one
-    // contiguous span per array); what the epilogue needs is fetched now so its latency is hidden
+    // ---- loads, ALL issued before anything waits for one of them (coalesced: a wave covers EPW consecutive
+    // envs = one contiguous span per array).  What the first controller needs comes first (loads return in
+    // order); what only the epilogue needs is fetched raw and decoded there, so its latency hides behind the
+    // sub-step loop (RG_LATE pins the first use of such a value to where it is decoded).
+#define RG_LATE(v) asm volatile("" : "+v"(v))
     float x = 0.0f, y = 0.0f, th = 0.0f, carry = 0.0f;
     int act = 4;
-    int steps = 0;
+    int steps_raw = 0;
     float agent_step = 0.0f, sr = 0.0f, cr = 0.0f;
     float st_ret = 0.0f, st_sum = 0.0f;
     int st_cnt = 0, st_steps = 0;
-    const bool stats = (!OBS_ONLY) && a.st.ep_return != nullptr;
+    const bool stats = (!OBS_ONLY) && q_ret != nullptr;
+    int pix = 0, reached = 0;  // ArcticTransport (pix feeds this step's goals)
     if (lane_ok) {
-        const float *X = a.st.poses + eN * 3;
+        const float *X = q_poses + eN * 3;
         x = X[ag];
         y = X[N + ag];
         th = X[2 * N + ag];
+        if constexpr (!OBS_ONLY) act = q_act[eN + ag];
+        if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) pix = q_pix[eN + ag];
         agent_step = p.agent_step[ag];
         if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
             sr = p.sensing_radius[ag];
             cr = p.capture_radius[ag];
         }
-        if constexpr (!OBS_ONLY) {
-            carry = a.st.carry_dist[eN + ag];
-            act = sv.actions[eN + ag];
-        }
+        if constexpr (!OBS_ONLY) carry = q_carry[eN + ag];
     }
+    int rc_raw = -1;  // reset_count, for the fused reset of an env that finishes in this launch
     if (env_ok) {
-        steps = a.st.episode_steps[e] + (OBS_ONLY ? 0 : 1);
+        steps_raw = q_steps[e];
+        if (!OBS_ONLY && a.auto_reset) rc_raw = q_rc[e];
         if (stats && ag == 0) {
-            st_ret = a.st.ep_return[e];
-            st_sum = a.st.done_return_sum[e];
-            st_cnt = a.st.done_count[e];
-            st_steps = a.st.done_steps_sum[e];
+            st_ret = q_ret[e];
+            st_sum = q_sum[e];
+            st_cnt = q_cnt[e];
+            st_steps = q_stp[e];
         }
     }
     // scenario state
     uint32_t sen_lo = 0, sen_hi = 0, cap_lo = 0, cap_hi = 0;  // PCP prey flags as bit masks (P <= 64)
-    uint8_t loaded = 0;                                      // Warehouse
+    int flag_raw[4] = {0, 0, 0, 0};                          // PCP, P <= 8: this lane's flag bytes, decoded in the epilogue
+    int loaded = 0;                                          // Warehouse
     float goal_x = 0.0f, goal_y = 0.0f;                      // Simple
     uint32_t grid_pre[6] = {0, 0, 0, 0, 0, 0};               // ArcticTransport
-    int goal_col = 1, pix = 0, reached = 0;
+    int goal_col = 1;
     int load = 0, zone0 = 0, zone1 = 0;                      // MaterialTransport
     int msg[4] = {0, 0, 0, 0};
     // PCP: up to 8 prey (the reference's configurations: 6) go straight into registers now -- every lane
@@ -332,64 +358,71 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     for (int t = 0; t < 8; ++t) prey_r[t] = make_float2(0.0f, 0.0f);
     static_assert(SCN != RG_SCN_ARCTIC_TRANSPORT || GW == 4, "ArcticTransport is a 4-agent scenario");
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-        const int P = p.num_prey;
-        if (env_ok) {
-            if (P <= 8) {
-                const float2 *src = reinterpret_cast<const float2 *>(a.st.prey_loc) + static_cast<size_t>(e) * P;
+        const int P = q_P;
+        if (P <= 8) {
+            if (env_ok) {
+                const float2 *src = reinterpret_cast<const float2 *>(q_prey) + static_cast<size_t>(e) * P;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) prey_r[t] = src[t < P ? t : P - 1];
-            } else {
-                for (int i = ag; i < 2 * P; i += GW) lds.prey[g][i] = a.st.prey_loc[static_cast<size_t>(e) * 2 * P + i];
+                if (ag < P) {
+                    flag_raw[0] = q_sen[static_cast<size_t>(e) * P + ag];
+                    flag_raw[1] = q_cap[static_cast<size_t>(e) * P + ag];
+                }
+                if constexpr (GW < 8)
+                    if (ag + GW < P) {
+                        flag_raw[2] = q_sen[static_cast<size_t>(e) * P + ag + GW];
+                        flag_raw[3] = q_cap[static_cast<size_t>(e) * P + ag + GW];
+                    }
             }
-            for (int i = ag; i < P; i += GW) {
-                const uint32_t sb = a.st.prey_sensed[static_cast<size_t>(e) * P + i] != 0;
-                const uint32_t cb = a.st.prey_captured[static_cast<size_t>(e) * P + i] != 0;
-                if (i < 32) {
-                    sen_lo |= sb << i;
-                    cap_lo |= cb << i;
-                } else {
-                    sen_hi |= sb << (i - 32);
-                    cap_hi |= cb << (i - 32);
+        } else {
+            if (env_ok) {
+                for (int i = ag; i < 2 * P; i += GW) lds.prey[g][i] = q_prey[static_cast<size_t>(e) * 2 * P + i];
+                for (int i = ag; i < P; i += GW) {
+                    const uint32_t sb = q_sen[static_cast<size_t>(e) * P + i] != 0;
+                    const uint32_t cb = q_cap[static_cast<size_t>(e) * P + i] != 0;
+                    if (i < 32) {
+                        sen_lo |= sb << i;
+                        cap_lo |= cb << i;
+                    } else {
+                        sen_hi |= sb << (i - 32);
+                        cap_hi |= cb << (i - 32);
+                    }
                 }
             }
-        }
-        sen_lo = group_or<GW>(sen_lo);
-        cap_lo = group_or<GW>(cap_lo);
-        if (P > 32) {
-            sen_hi = group_or<GW>(sen_hi);
-            cap_hi = group_or<GW>(cap_hi);
+            sen_lo = group_or<GW>(sen_lo);
+            cap_lo = group_or<GW>(cap_lo);
+            if (P > 32) {
+                sen_hi = group_or<GW>(sen_hi);
+                cap_hi = group_or<GW>(cap_hi);
+            }
         }
     } else if constexpr (SCN == RG_SCN_WAREHOUSE) {
-        if (lane_ok) loaded = a.st.loaded[eN + ag];
+        if (lane_ok) loaded = q_loaded[eN + ag];
     } else if constexpr (SCN == RG_SCN_SIMPLE) {
         if (env_ok) {
-            goal_x = a.st.prey_loc[static_cast<size_t>(e) * 2];
-            goal_y = a.st.prey_loc[static_cast<size_t>(e) * 2 + 1];
+            goal_x = q_prey[static_cast<size_t>(e) * 2];
+            goal_y = q_prey[static_cast<size_t>(e) * 2 + 1];
         }
     } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
         if (env_ok) {
             // 96 terrain bytes = 24 dwords: 6 per lane of the group (GW = 4)
-            const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(a.st.grid + static_cast<size_t>(e) * 96);
+            const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(q_grid + static_cast<size_t>(e) * 96);
 #pragma unroll
             for (int t = 0; t < 6; ++t) grid_pre[t] = gsrc[ag * 6 + t];
-            goal_col = a.st.goal_col[e];
+            goal_col = q_gcol[e];
         }
-        if (lane_ok) {
-            pix = a.st.pixel_type[eN + ag];
-            reached = a.st.reached_goal[eN + ag];
-        }
+        if (lane_ok) reached = q_reached[eN + ag];
     } else {
         if (env_ok) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                msg[i] = a.st.messages[4 * e + i];
-                if constexpr (!OBS_ONLY)
-                    if (i < N) msg[i] = sv.actions[eN + i] % 4;  // MaterialTransport.py:119-120
+            for (int i = 0; i < 4; ++i) {  // raw: the `% 4` of MaterialTransport.py:119-120 happens in the epilogue
+                if (OBS_ONLY || i >= N) msg[i] = q_msg[4 * e + i];
+                else msg[i] = q_act[eN + i];
             }
-            zone0 = a.st.zone_load[2 * e];
-            zone1 = a.st.zone_load[2 * e + 1];
+            zone0 = q_zone[2 * e];
+            zone1 = q_zone[2 * e + 1];
         }
-        if (lane_ok) load = a.st.load[eN + ag];
+        if (lane_ok) load = q_load[eN + ag];
     }
 
     int viol = 0, max_sweeps = 0;
@@ -598,11 +631,26 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     bool done = false;
     int remaining = -1;
     float reward = 0.0f;
+    RG_LATE(steps_raw);
+    const int steps = steps_raw + (OBS_ONLY ? 0 : 1);
 
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-        const int P = p.num_prey;
+        const int P = q_P;
         const float sr2 = sr * sr, cr2 = cr * cr;
         if (P > 8) __syncthreads();  // LDS prey block visible (single-wave workgroup: waitcnt + s_barrier)
+        if (P <= 8) {  // the flag bytes fetched in the prologue -> bit masks of the env
+            RG_LATE(flag_raw[0]);
+            RG_LATE(flag_raw[1]);
+            uint32_t sb = (flag_raw[0] != 0 ? 1u : 0u) << ag, cb = (flag_raw[1] != 0 ? 1u : 0u) << ag;
+            if constexpr (GW < 8) {
+                RG_LATE(flag_raw[2]);
+                RG_LATE(flag_raw[3]);
+                sb |= (flag_raw[2] != 0 ? 1u : 0u) << (ag + GW);
+                cb |= (flag_raw[3] != 0 ? 1u : 0u) << (ag + GW);
+            }
+            sen_lo = group_or<GW>(sb);
+            cap_lo = group_or<GW>(cb);
+        }
         uint32_t nsen_lo = sen_lo, nsen_hi = sen_hi, ncap_lo = cap_lo, ncap_hi = cap_hi;
         // The prey block is scanned four at a time (LDS reads in flight together).  scan(lo, hi, f)
         // calls f(i, prey_x, prey_y, d2) for i in [lo, hi).
@@ -774,7 +822,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     }
                 }
                 done = steps > p.max_episode_steps;
-                if (lane_ok) a.st.loaded[eN + ag] = loaded;
+                if (lane_ok) a.st.loaded[eN + ag] = static_cast<uint8_t>(loaded);
             }
         }
     } else if constexpr (SCN == RG_SCN_SIMPLE) {  // scenarios/Simple/simple.py:155-225
@@ -884,6 +932,11 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             }
         }
     } else {  // a16 MaterialTransport (MaterialTransport.py:113-189)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            RG_LATE(msg[i]);
+            if (!OBS_ONLY && i < N) msg[i] = msg[i] % 4;  // MaterialTransport.py:119-120
+        }
         if (lane_ok) {
             obs_row[0] = x;
             obs_row[1] = y;
@@ -986,6 +1039,10 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             if (ag == 0) {
                 a.st.episode_steps[e] = steps;
                 if (stats) {  // misc.py:178-185: episodeReward += reward[0] | sum(reward)
+                    RG_LATE(st_ret);
+                    RG_LATE(st_sum);
+                    RG_LATE(st_cnt);
+                    RG_LATE(st_steps);
                     float ret = st_ret + (p.shared_reward ? reward : rsum);
                     if (done) {
                         a.st.done_return_sum[e] = st_sum + ret;
@@ -1005,7 +1062,8 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         // ---- fused auto-reset of finished envs (scenario.reset(); ~1 env in 70 per step)
         if (a.auto_reset && __any(env_ok & done)) {
             __syncthreads();  // the wave's state stores are issued before the resetting lanes rewrite them
-            reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done);
+            RG_LATE(rc_raw);
+            reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done, rc_raw);
         }
         RG_STAMP(6);  // reset done
 #ifdef RG_STAMPS

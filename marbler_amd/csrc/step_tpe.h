@@ -253,40 +253,47 @@ __device__ __forceinline__ void write_obs_with_neighbours(const float (&x)[N], c
 // ------------------------------------------------------------------ one env step on one lane
 // returns whether the episode ended (roboEnv.py:38-96 + the scenario's step())
 template <int SCN, int N>
-__device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv, const int e) {
+__device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv, const int e, int &rc_raw) {
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
     const size_t eN = static_cast<size_t>(e) * N;
 
-    // ---- loads
+    // ---- kernel arguments the loads need, fetched together (one scalar-memory round trip instead of one per
+    // field at its first use; see step_group.h), then ALL the loads before anything waits for one of them
+    const float *q_poses = a.st.poses, *q_carry = a.st.carry_dist, *q_ret = a.st.ep_return, *q_sum = a.st.done_return_sum;
+    const int32_t *q_steps = a.st.episode_steps, *q_act = sv.actions, *q_cnt = a.st.done_count, *q_stp = a.st.done_steps_sum;
+    asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp));
+#define RG_LATE(v) asm volatile("" : "+v"(v))
     float x[N], y[N], th[N], acc[N], last[N];
     int act[N];
+    int pix[N];
     {
-        const float *X = a.st.poses + eN * 3;
+        const float *X = q_poses + eN * 3;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             x[i] = X[i];
             y[i] = X[N + i];
             th[i] = X[2 * N + i];
-            acc[i] = a.st.carry_dist[eN + i];  // dist incl. the pending sub-step
+            act[i] = q_act[eN + i];
             last[i] = 0.0f;
-            act[i] = sv.actions[eN + i];
         }
+        if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) pix[i] = a.st.pixel_type[eN + i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = q_carry[eN + i];  // dist incl. the pending sub-step (first used at the period end)
     }
-    const int steps = a.st.episode_steps[e] + 1;
-    const bool stats = a.st.ep_return != nullptr;
+    int steps_raw = q_steps[e];
+    if (a.auto_reset) rc_raw = a.st.reset_count[e];  // for the fused reset, should this env finish
+    const bool stats = q_ret != nullptr;
     float st_ret = 0.0f, st_sum = 0.0f;
     int st_cnt = 0, st_steps = 0;
     if (stats) {
-        st_ret = a.st.ep_return[e];
-        st_sum = a.st.done_return_sum[e];
-        st_cnt = a.st.done_count[e];
-        st_steps = a.st.done_steps_sum[e];
-    }
-    int pix[N];
-    if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) pix[i] = a.st.pixel_type[eN + i];
+        st_ret = q_ret[e];
+        st_sum = q_sum[e];
+        st_cnt = q_cnt[e];
+        st_steps = q_stp[e];
     }
 
     // ---- a1 goal generation
@@ -469,6 +476,8 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     bool done = false;
     int remaining = -1;
     float reward[N];
+    RG_LATE(steps_raw);
+    const int steps = steps_raw + 1;
 
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
@@ -488,9 +497,21 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             qx[i] = -5.0f;
             qy[i] = -5.0f;
         }
-        for (int q = 0; q < P; ++q) {  // a11 tracking + a13 nearest prey, prey by prey (PredatorCapturePrey.py:72-95)
-            const float px = pl[2 * q], py = pl[2 * q + 1];
-            bool sensed = sen[q] != 0, captured = cap[q] != 0;
+        // up to 8 prey (the reference's configurations: 6): the whole block and its flags are fetched before the
+        // loop -- one memory round trip instead of one per prey
+        float2 pre_xy[8];
+        int pre_s[8], pre_c[8];
+        const bool pre = P <= 8;
+        if (pre) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int tt = t < P ? t : P - 1;
+                pre_xy[t] = reinterpret_cast<const float2 *>(pl)[tt];
+                pre_s[t] = sen[tt];
+                pre_c[t] = cap[tt];
+            }
+        }
+        auto prey_step = [&](float px, float py, bool sensed, bool captured, int q) {
             unseen0 += !sensed;
             left0 += !captured;
             float d2[N];
@@ -517,6 +538,13 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 qy[i] = take ? py : qy[i];
                 closest[i] = take ? d2[i] : closest[i];
             }
+        };
+        if (pre) {  // a11 tracking + a13 nearest prey, prey by prey (PredatorCapturePrey.py:72-95)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < P) prey_step(pre_xy[t].x, pre_xy[t].y, pre_s[t] != 0, pre_c[t] != 0, t);
+        } else {
+            for (int q = 0; q < P; ++q) prey_step(pl[2 * q], pl[2 * q + 1], sen[q] != 0, cap[q] != 0, q);
         }
         if (p.capability_aware) {
             float own[N][6];
@@ -772,6 +800,10 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     {
         float *X = a.st.poses + eN * 3;
         float rsum = 0.0f;
+        RG_LATE(st_ret);
+        RG_LATE(st_sum);
+        RG_LATE(st_cnt);
+        RG_LATE(st_steps);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             X[i] = x[i];
@@ -816,7 +848,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     for (int t = 0; t < num_steps; ++t) {
         if (t) __syncthreads();  // the previous step's stores and resets are visible to the wave
         bool done = false;
-        if (e < a.E) done = step_env<SCN, N>(a, step_view(a, t, N, a.p.obs_dim), e);
+        int rc_raw = -1;
+        if (e < a.E) done = step_env<SCN, N>(a, step_view(a, t, N, a.p.obs_dim), e, rc_raw);
         // fused auto-reset (scenario.reset(); ~1 env in 70 per step): the whole wave resets each finished
         // env together, as one 64-lane group of the shared sampler
         if (a.auto_reset) {
@@ -825,7 +858,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
             while (todo) {
                 const int i = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                reset_group<SCN, WAVE>(a, lds, chunk * WAVE + i, 0, threadIdx.x, true);
+                reset_group<SCN, WAVE>(a, lds, chunk * WAVE + i, 0, threadIdx.x, true, __builtin_amdgcn_readlane(rc_raw, i));
             }
         }
     }
