@@ -155,6 +155,13 @@ CASES = [
     # `robotarium: True`: the controller (and its QP) on every sub-iteration (roboEnv.py:63)
     ("pcp_n5_robotarium", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "robotarium": True}, [121], 90, 0.35),
     ("mt_n4_robotarium", "MaterialTransport", {"robotarium": True}, [123], 40, 0.3),
+    # the other barrier certificate (controller.py:15-16: r = 0.17, no unsafe gain), violations not penalised
+    # (roboEnv.py:82: no early exit, robots may overlap), the other upstream collision test (Appendix A.4)
+    ("pcp_n5_cert_default", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "barrier_certificate": "default"},
+     [131, 132], 120, 0.35),
+    ("warehouse_n8_no_penalty", "Warehouse", {"n_agents": 8, "penalize_violations": False}, [141], 140, 0.5),
+    ("pcp_n5_center_collision", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "collision_variant": "center"},
+     [151], 170, 1.0),
 ]
 
 
@@ -165,7 +172,7 @@ def run_case(name, scenario, overrides, seeds, steps, eps):
     for seed in seeds:
         ov = dict(overrides)
         ov["seed"] = seed
-        w, cfg = rh.make_reference_wrapper(scenario, ov)
+        w, cfg = rh.make_reference_wrapper(scenario, ov, collision_variant=ov.get("collision_variant", "offset"))
         cfg_out = cfg
         rng = np.random.RandomState(1000 + seed)
         rh.quiet_reset(w)
