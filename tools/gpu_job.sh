@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 if [[ " $* " != *" notest "* ]]; then
   timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1 || { tail -30 $OUT/pytest.log; exit 1; }
   tail -3 $OUT/pytest.log
+  timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1 || { tail -20 $OUT/smoke.log; exit 7; }
+  tail -1 $OUT/smoke.log
 fi
 timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 2; }
 python - <<PY
