@@ -233,13 +233,12 @@ def rollout_leg(env, dev, n_act, seed, launches=16):
             "agent_steps_per_s": env.E * env.N / (ms * 1e-3), "hbm_achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
 
 
-def saturated_leg(dev, overrides):
-    """The same step at a batch that fills the chip (524288 envs, thread-per-env kernel): where the
-    path stands against the HBM roof when launch latency no longer binds.  Reported beside the
-    headline, never as `value`."""
+def saturated_leg(dev, overrides, E=SATURATED_ENVS):
+    """The same step at a batch that fills the chip (524288 envs = 8 waves per SIMD, and 2097152 = 32, where the
+    ragged end of the launch weighs less; thread-per-env kernel): where the path stands against the HBM roof
+    when launch latency no longer binds.  Reported beside the headline, never as `value`."""
     import torch
     from marbler_amd import VecRobotariumEnv
-    E = SATURATED_ENVS
     env = VecRobotariumEnv("PredatorCapturePrey", E, overrides=overrides, device=dev, seed=0, auto_reset=True)
     gen = torch.Generator(device=dev)
     gen.manual_seed(99)
@@ -521,6 +520,7 @@ def main():
         if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey":
             out["rollout"] = rollout_leg(env, dev, n_act, 777)
             out["saturated"] = saturated_leg(dev, overrides)
+            out["saturated_2m"] = saturated_leg(dev, overrides, 4 * SATURATED_ENVS)
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
         print(json.dumps(out))
