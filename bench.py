@@ -435,15 +435,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()                                # HIP events are created on first use: not inside the timed region
+    ev1.record()
     for i in range(W):
         step(ptrs[i % n_batches])
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(K):
         rc = step(ptrs[(W + i) % n_batches])
     ev1.record()
+    while not ev1.query():                      # poll instead of sleeping on the completion signal, then the contract's
+        pass                                    # synchronize (returns at once: the stream is drained)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0          # this rank's K steps, device-complete
     barrier()
