@@ -78,6 +78,10 @@ int main(int argc, char **argv) {
     st.done_return_sum = dev_zeros<float>(E);
     st.done_count = dev_zeros<int32_t>(E);
     st.done_steps_sum = dev_zeros<int32_t>(E);
+    // scratch of the lane-group kernel: every env's next initial state, drawn ahead of time (optional)
+    st.next_init = dev_zeros<float>((size_t)E * rg_next_init_stride(&p));
+    st.next_episode = dev_zeros<int32_t>(E);
+    HIP_OK(hipMemset(st.next_episode, 0xFF, (size_t)E * sizeof(int32_t)));   // -1 = none drawn yet
 
     rg_step_io io;
     memset(&io, 0, sizeof(io));

@@ -126,6 +126,14 @@ typedef struct rg_state {
     float *done_return_sum; /* [E] sum of the returns of the episodes this env has finished */
     int32_t *done_count;    /* [E] number of episodes this env has finished */
     int32_t *done_steps_sum;/* [E] total length of those episodes */
+    /* Optional scratch of the lane-group step kernel (both NULL, or both set; contents are derived data, never part of a
+     * snapshot): an env's NEXT initial state, drawn ahead of time at the end of a launch in which the env did not finish,
+     * so that the launch in which it does finish copies it instead of running the sampler on its critical path.
+     * next_init: [E][rg_next_init_stride(params)] floats; next_episode: [E], the episode index (= reset_count) the block
+     * was drawn for, -1 = none.  Initialise next_episode to -1.  The library invalidates the blocks itself when the
+     * `seed` argument of rg_step / rg_rollout changes. */
+    float *next_init;
+    int32_t *next_episode;
 } rg_state;
 
 /* Everything Wrapper.step returns (wrapper.py:41-44), batched. */
@@ -147,6 +155,8 @@ const char *rg_last_error(void);
 int rg_sizeof_params(void);
 int rg_sizeof_state(void);
 int rg_sizeof_step_io(void);
+/* floats per env of rg_state.next_init for this parameter block */
+int rg_next_init_stride(const rg_scenario_params *params);
 
 /* Replaces Wrapper.__init__ -> scenario.__init__ -> roboEnv.__init__ -> Controller.__init__
  * (wrapper.py:20-34, PredatorCapturePrey.py:15-59, roboEnv.py:12-24, controller.py:5-18).

@@ -60,7 +60,8 @@ class RgState(C.Structure):
                 ("zone_load", C.c_void_p), ("messages", C.c_void_p), ("grid", C.c_void_p),
                 ("goal_col", C.c_void_p), ("pixel_type", C.c_void_p), ("reached_goal", C.c_void_p),
                 ("ep_return", C.c_void_p),
-                ("done_return_sum", C.c_void_p), ("done_count", C.c_void_p), ("done_steps_sum", C.c_void_p)]
+                ("done_return_sum", C.c_void_p), ("done_count", C.c_void_p), ("done_steps_sum", C.c_void_p),
+                ("next_init", C.c_void_p), ("next_episode", C.c_void_p)]
 
 
 class RgStepIO(C.Structure):
@@ -76,7 +77,7 @@ class RgActorWeights(C.Structure):
                 ("n_actions", C.c_int32), ("use_rnn", C.c_int32), ("gru_packed", C.c_int32)]
 
 
-EXPORTS = ("rg_abi_version", "rg_last_error", "rg_sizeof_params", "rg_sizeof_state", "rg_sizeof_step_io",
+EXPORTS = ("rg_abi_version", "rg_last_error", "rg_sizeof_params", "rg_sizeof_state", "rg_sizeof_step_io", "rg_next_init_stride",
            "rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs",
            "rg_actor_forward", "rg_actor_pack_gru", "rg_actor_last_error")
 
@@ -104,6 +105,8 @@ def load():
     lib.rg_last_error.restype = C.c_char_p
     lib.rg_create.restype = C.c_void_p
     lib.rg_create.argtypes = [C.POINTER(RgScenarioParams), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
+    lib.rg_next_init_stride.argtypes = [C.POINTER(RgScenarioParams)]
+    lib.rg_next_init_stride.restype = C.c_int
     lib.rg_destroy.argtypes = [C.c_void_p]
     lib.rg_bind_state.argtypes = [C.c_void_p, C.POINTER(RgState)]
     lib.rg_set_stream.argtypes = [C.c_void_p, C.c_void_p]

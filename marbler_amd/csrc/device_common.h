@@ -236,11 +236,49 @@ __device__ __forceinline__ void cell_xy(const rg_grid &grid, int cell, float &x,
     y = (fy + grid.oy1) + grid.oy2;
 }
 
+// Where a draw goes.  commit = true: the env's state arrays, and the episode really starts (flags and counters cleared,
+// reset_count advanced).  commit = false: the env's block of rg_state.next_init -- the lane-group step kernel draws an
+// env's NEXT initial state ahead of time, at the end of a launch in which the env did not finish, so that the launch in
+// which it does finish (typically its slowest wavefront: a near-collision env) only copies it (step_group.h).
+struct ResetDst {
+    float *poses;     // [3][N]
+    float *prey;      // [P][2]   PredatorCapturePrey, Simple
+    int32_t *zone;    // [2]      MaterialTransport
+    uint8_t *grid;    // [96]     ArcticTransport
+    int32_t *gcol;    //          ArcticTransport
+    bool commit;
+};
+__device__ __forceinline__ ResetDst reset_dst_state(const KernelArgs &a, int e) {
+    const int N = a.p.n_agents, P = a.p.num_prey;
+    ResetDst d;
+    d.poses = a.st.poses + static_cast<size_t>(e) * 3 * N;
+    d.prey = a.st.prey_loc ? a.st.prey_loc + static_cast<size_t>(e) * 2 * P : nullptr;
+    d.zone = a.st.zone_load ? a.st.zone_load + 2 * static_cast<size_t>(e) : nullptr;
+    d.grid = a.st.grid ? a.st.grid + static_cast<size_t>(e) * 96 : nullptr;
+    d.gcol = a.st.goal_col ? a.st.goal_col + e : nullptr;
+    d.commit = true;
+    return d;
+}
+// layout of one env's block of next_init (next_stride floats): poses [3N] | prey [2P] or zone loads [2] (as ints) or
+// terrain [24 dwords] + goal column
+__device__ __forceinline__ ResetDst reset_dst_next(const KernelArgs &a, int e) {
+    const int N = a.p.n_agents;
+    float *base = a.st.next_init + static_cast<size_t>(e) * a.next_stride;
+    ResetDst d;
+    d.poses = base;
+    d.prey = base + 3 * N;
+    d.zone = reinterpret_cast<int32_t *>(base + 3 * N);
+    d.grid = reinterpret_cast<uint8_t *>(base + 3 * N);
+    d.gcol = reinterpret_cast<int32_t *>(base + 3 * N + 24);
+    d.commit = false;
+    return d;
+}
+
 // episode_pre >= 0: the env's reset_count, already fetched by the caller (the step kernels prefetch it with the rest of
 // the state, so a finished env's reset does not start with a memory round trip of its own)
 template <int SCN, int GW>
 __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, int e, int g, int ag, bool do_reset,
-                                            int episode_pre = -1) {
+                                            int episode_pre, const ResetDst &dst) {
     const rg_scenario_params &p = a.p;
     const int N = p.n_agents;
     if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
@@ -269,21 +307,25 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
                 int val = static_cast<int>((static_cast<uint64_t>(lds.draws[g][i]) * 3u) >> 32);
                 if (row <= 1 && (col == gc || col == gc - 1)) val = 3;
                 if (row == 7 && col >= 1 && col <= 10) val = 0;
-                a.st.grid[static_cast<size_t>(e) * CELLS + i] = static_cast<uint8_t>(val);
+                dst.grid[i] = static_cast<uint8_t>(val);
             }
             if (ag < N) {
-                float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
+                float *X = dst.poses;
                 X[ag] = ag == 0 ? -0.3f : ag == 1 ? 0.3f : ag == 2 ? -0.9f : 0.9f;  // ArcticTransport.py:30-33
                 X[N + ag] = -0.8f;
                 X[2 * N + ag] = 1.57079637050628662109375f;
-                a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
-                a.st.pixel_type[static_cast<size_t>(e) * N + ag] = 0;
-                a.st.reached_goal[static_cast<size_t>(e) * N + ag] = 0;
+                if (dst.commit) {
+                    a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
+                    a.st.pixel_type[static_cast<size_t>(e) * N + ag] = 0;
+                    a.st.reached_goal[static_cast<size_t>(e) * N + ag] = 0;
+                }
             }
             if (ag == 0) {
-                a.st.goal_col[e] = gc;
-                a.st.reset_count[e] = episode + 1;
-                a.st.episode_steps[e] = 0;
+                *dst.gcol = gc;
+                if (dst.commit) {
+                    a.st.reset_count[e] = episode + 1;
+                    a.st.episode_steps[e] = 0;
+                }
             }
         }
         return;
@@ -312,21 +354,23 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
         float x, y;
         cell_xy(p.agent_grid, lds.sel[g][0][ag], x, y);
         const float th = uniform01(lds.draws[g][ZD + N + ag]) * 6.283185482025146484375f - 3.1415927410125732421875f;
-        float *X = a.st.poses + static_cast<size_t>(e) * 3 * N;
+        float *X = dst.poses;
         X[ag] = x;
         X[N + ag] = y;
         X[2 * N + ag] = p.keep_theta ? th : 0.0f;
-        a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
-        if constexpr (SCN == RG_SCN_WAREHOUSE) a.st.loaded[static_cast<size_t>(e) * N + ag] = 0;
-        if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
-            a.st.load[static_cast<size_t>(e) * N + ag] = 0;
-            if (ag < 4) a.st.messages[4 * e + ag] = 0;
+        if (dst.commit) {
+            a.st.carry_dist[static_cast<size_t>(e) * N + ag] = 0.0f;
+            if constexpr (SCN == RG_SCN_WAREHOUSE) a.st.loaded[static_cast<size_t>(e) * N + ag] = 0;
+            if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
+                a.st.load[static_cast<size_t>(e) * N + ag] = 0;
+                if (ag < 4) a.st.messages[4 * e + ag] = 0;
+            }
         }
     }
     if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {  // MaterialTransport.py:99-100
         if (do_reset && ag < 2) {
             const float mean = ag == 0 ? p.zone1_mean : p.zone2_mean, sd = ag == 0 ? p.zone1_std : p.zone2_std;
-            a.st.zone_load[2 * e + ag] = normal_int(lds.draws[g][2 * ag], lds.draws[g][2 * ag + 1], mean, sd);
+            dst.zone[ag] = normal_int(lds.draws[g][2 * ag], lds.draws[g][2 * ag + 1], mean, sd);
         }
     }
     if constexpr (HAS_PREY) {
@@ -334,20 +378,29 @@ __device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, i
             for (int i = ag; i < P; i += GW) {
                 float x, y;
                 cell_xy(p.prey_grid, lds.sel[g][1][i], x, y);
-                float *pl = a.st.prey_loc + (static_cast<size_t>(e) * P + i) * 2;
+                float *pl = dst.prey + 2 * i;
                 pl[0] = x;
                 pl[1] = y;
                 if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
-                    a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
-                    a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
+                    if (dst.commit) {
+                        a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
+                        a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
+                    }
                 }
             }
         }
     }
-    if (do_reset && ag == 0) {
+    if (do_reset && ag == 0 && dst.commit) {
         a.st.reset_count[e] = episode + 1;
         a.st.episode_steps[e] = 0;
     }
+}
+
+// the draw straight into the env's state: scenario.reset()
+template <int SCN, int GW>
+__device__ __forceinline__ void reset_group(const KernelArgs &a, Lds<GW> &lds, int e, int g, int ag, bool do_reset,
+                                            int episode_pre = -1) {
+    reset_group<SCN, GW>(a, lds, e, g, ag, do_reset, episode_pre, reset_dst_state(a, e));
 }
 
 }  // namespace rg

@@ -74,9 +74,19 @@ struct KernelArgs {
     int32_t num_steps;  // env steps per launch (rg_step: 1); io and actions carry a leading dimension of this size
     int32_t auto_reset;
     int32_t reset_flags;  // rg_reset: RG_RESET_*
+    int32_t next_stride;  // floats per env of st.next_init (0 = the precomputed-reset blocks are not in use)
     int64_t env_offset;
     uint64_t seed;
 };
+
+// floats per env of rg_state.next_init: poses [3N] | prey [2P] / zone loads [2] / terrain [24] + goal column, rounded up to 4
+inline int next_init_stride(const rg_scenario_params &p) {
+    int w = 3 * p.n_agents;
+    if (p.scenario == RG_SCN_PREDATOR_CAPTURE_PREY || p.scenario == RG_SCN_SIMPLE) w += 2 * p.num_prey;
+    else if (p.scenario == RG_SCN_MATERIAL_TRANSPORT) w += 2;
+    else if (p.scenario == RG_SCN_ARCTIC_TRANSPORT) w += 25;
+    return (w + 3) & ~3;
+}
 
 hipError_t launch_step(const KernelArgs &a, bool obs_only, hipStream_t stream);
 hipError_t launch_reset(const KernelArgs &a, hipStream_t stream);

@@ -23,6 +23,8 @@ struct rg_handle {
     hipStream_t stream;
     bool bound;
     bool use_tpe;  // step with the thread-per-env kernel (robogym_tpe.hip) instead of the lane-group kernel
+    bool seed_seen;      // the precomputed-reset blocks (rg_state.next_init) were drawn with last_seed
+    uint64_t last_seed;
 };
 
 // Which step kernel: both give identical results.  The lane-group kernel has the shorter chain for
@@ -117,6 +119,10 @@ const char *rg_last_error(void) { return g_err; }
 int rg_sizeof_params(void) { return static_cast<int>(sizeof(rg_scenario_params)); }
 int rg_sizeof_state(void) { return static_cast<int>(sizeof(rg_state)); }
 int rg_sizeof_step_io(void) { return static_cast<int>(sizeof(rg_step_io)); }
+int rg_next_init_stride(const rg_scenario_params *params) {
+    if (check_params(params) != 0) return -1;
+    return rg::next_init_stride(*params);
+}
 
 rg_handle *rg_create(const rg_scenario_params *params, int32_t num_envs, int64_t env_offset, int32_t device,
                      void *hip_stream) {
@@ -147,6 +153,8 @@ rg_handle *rg_create(const rg_scenario_params *params, int32_t num_envs, int64_t
     h->device = device;
     h->stream = static_cast<hipStream_t>(hip_stream);
     h->bound = false;
+    h->seed_seen = false;
+    h->last_seed = 0;
     h->use_tpe = rg::tpe_supported(*params) && num_envs >= tpe_min_envs(*params);
     if (const char *force = getenv("RG_STEP_KERNEL")) {
         if (!strcmp(force, "group")) h->use_tpe = false;
@@ -195,6 +203,8 @@ int rg_bind_state(rg_handle *h, const rg_state *st) {
     const int nstat = (st->ep_return != nullptr) + (st->done_return_sum != nullptr) + (st->done_count != nullptr) +
                       (st->done_steps_sum != nullptr);
     if (nstat != 0 && nstat != 4) return fail(-25, "rollout statistics arrays: set all four or none");
+    if ((st->next_init != nullptr) != (st->next_episode != nullptr)) return fail(-25, "next_init / next_episode: set both or none");
+    if (reinterpret_cast<uintptr_t>(st->next_init) & 15u) return fail(-26, "next_init must be 16-byte aligned");
     h->state = *st;
     h->bound = true;
     return 0;
@@ -210,6 +220,21 @@ static int fill_args(rg_handle *h, rg::KernelArgs &a) {
     a.E = h->num_envs;
     a.num_steps = 1;
     a.env_offset = h->env_offset;
+    // the precomputed-reset blocks serve the lane-group kernel (latency regime); the thread-per-env kernel ignores them
+    a.next_stride = (!h->use_tpe && h->state.next_init) ? rg::next_init_stride(h->params) : 0;
+    return 0;
+}
+
+// The blocks of rg_state.next_init are functions of (seed, global env, episode): a new seed makes them stale.
+static int sync_seed(rg_handle *h, uint64_t seed) {
+    if (h->state.next_episode && (!h->seed_seen || h->last_seed != seed)) {
+        if (h->seed_seen) {
+            const hipError_t err = hipMemsetAsync(h->state.next_episode, 0xFF, sizeof(int32_t) * static_cast<size_t>(h->num_envs), h->stream);
+            if (err != hipSuccess) return fail(-30, "hipMemsetAsync(next_episode) failed: %s", hipGetErrorString(err));
+        }
+        h->seed_seen = true;
+        h->last_seed = seed;
+    }
     return 0;
 }
 
@@ -245,6 +270,7 @@ int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t 
     a.auto_reset = auto_reset;
     a.seed = seed;
     RG_ON_DEVICE(h);
+    if (int rc = sync_seed(h, seed)) return rc;
     return launched(h->use_tpe ? rg::launch_step_tpe(a, h->stream) : rg::launch_step(a, false, h->stream));
 }
 
@@ -266,6 +292,7 @@ int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg
     a.auto_reset = auto_reset;
     a.seed = seed;
     RG_ON_DEVICE(h);
+    if (int rc = sync_seed(h, seed)) return rc;
     if (!h->use_tpe) return launched(rg::launch_rollout(a, h->stream));
     // thread-per-env: the multi-step kernel holds more values live (313 VGPRs at N = 5: one wave per
     // SIMD); it pays while the batch is at most one wave per SIMD (the latency regime), beyond that

@@ -262,7 +262,9 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
 // NT: the agent count when it is a compile-time constant (instantiated for GW = 8: 5..8), 0 = read
 // it from the parameter block.  One env step of the wave's envs; `sv` = this step's slice of the
 // action and output arrays.
-template <int SCN, int GW, bool OBS_ONLY, int NT>
+// AHEAD: use (and keep filled) the drawn-ahead initial states of rg_state.next_init.  Off in the multi-step launch: there
+// the launch costs the MEAN wavefront, and drawing ahead moves the sampler's work without removing any.
+template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD>
 __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, const StepView &sv) {
     constexpr int EPW = WAVE / GW;  // envs per wave
 #ifdef RG_STAMPS
@@ -277,10 +279,13 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     // before the first controller (tools/stamp_probe.py).  The empty asm makes all of them live here: one trip.
     const float *q_poses = a.st.poses, *q_carry = a.st.carry_dist, *q_ret = a.st.ep_return, *q_sum = a.st.done_return_sum;
     const int32_t *q_steps = a.st.episode_steps, *q_act = sv.actions, *q_cnt = a.st.done_count, *q_stp = a.st.done_steps_sum;
-    const int32_t *q_rc = a.st.reset_count;
+    const int32_t *q_rc = a.st.reset_count, *q_nep = AHEAD ? a.st.next_episode : nullptr;
+    const float *q_nin = AHEAD ? a.st.next_init : nullptr;
+    const int q_nst = AHEAD ? a.next_stride : 0;
     const int q_E = a.E, q_epw = a.envs_per_wave, q_P = p.num_prey, q_N = p.n_agents, q_G = gridDim.x;
     asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp),
                  "s"(q_E), "s"(q_epw), "s"(q_P), "s"(q_N), "s"(q_G), "s"(q_rc));
+    if constexpr (AHEAD) asm volatile("" ::"s"(q_nep), "s"(q_nin), "s"(q_nst));
     const float *q_prey = a.st.prey_loc;
     const uint8_t *q_sen = a.st.prey_sensed, *q_cap = a.st.prey_captured, *q_loaded = a.st.loaded, *q_grid = a.st.grid;
     const uint8_t *q_pix = a.st.pixel_type, *q_reached = a.st.reached_goal;
@@ -331,9 +336,40 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         if constexpr (!OBS_ONLY) carry = q_carry[eN + ag];
     }
     int rc_raw = -1;  // reset_count, for the fused reset of an env that finishes in this launch
+    // The env's NEXT initial state, drawn ahead of time into its block of next_init (device_common.h ResetDst) at the
+    // end of an earlier launch: fetched now with everything else, so that an env that finishes in this launch -- as a
+    // rule the slowest wavefront's, a near-collision env -- starts its next episode with a handful of stores instead of
+    // the sampler (Philox, Fisher-Yates through LDS: ~2 k cycles at the very end of the launch's critical path).
+    const bool ahead = AHEAD && (!OBS_ONLY) && q_nst > 0 && a.auto_reset;
+    int nx_tag = -2;                               // episode the block was drawn for
+    float nx_pose[3] = {0.0f, 0.0f, 0.0f};         // this lane's agent
+    float nx_a = 0.0f, nx_b = 0.0f;                // PCP / Simple: prey `ag` (x, y); MaterialTransport: zone load `ag` (bits)
+    uint32_t nx_grid[7] = {0, 0, 0, 0, 0, 0, 0};   // ArcticTransport: this lane's 6 terrain dwords + the goal column
     if (env_ok) {
         steps_raw = q_steps[e];
         if (!OBS_ONLY && a.auto_reset) rc_raw = q_rc[e];
+        if (ahead) {
+            const float *nb = q_nin + static_cast<size_t>(e) * q_nst;
+            nx_tag = q_nep[e];
+            if (ag < N) {
+                nx_pose[0] = nb[ag];
+                nx_pose[1] = nb[N + ag];
+                nx_pose[2] = nb[2 * N + ag];
+            }
+            if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY || SCN == RG_SCN_SIMPLE) {
+                if (ag < q_P) {
+                    nx_a = nb[3 * N + 2 * ag];
+                    nx_b = nb[3 * N + 2 * ag + 1];
+                }
+            } else if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
+                if (ag < 2) nx_a = nb[3 * N + ag];
+            } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+                const uint32_t *gb = reinterpret_cast<const uint32_t *>(nb + 3 * N);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) nx_grid[t] = gb[ag * 6 + t];
+                nx_grid[6] = gb[24];
+            }
+        }
         if (stats && ag == 0) {
             st_ret = q_ret[e];
             st_sum = q_sum[e];
@@ -426,6 +462,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     }
 
     int viol = 0, max_sweeps = 0;
+    bool replayed = false;  // wave-uniform: some chunk of this step went through the exact-test replay
     float dist = 0.0f;
     if constexpr (!OBS_ONLY) {
 #ifdef RG_STAMPS
@@ -542,6 +579,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                 int dmin = dmin_u[0];
                 static_for<1, C>([&](auto UU) { dmin = dmin_u[decltype(UU)::value] < dmin ? dmin_u[decltype(UU)::value] : dmin; });
                 if (penalize && __any((dmin <= thr_pre) | bnd_any)) {
+                    replayed = true;
                     // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94): the
                     // boundary test on every sub-step (per lane, cheap), the pair rounds only on the sub-steps
                     // whose own pre-test fired somewhere in the wave (robots cross the 3 mm pre-test band
@@ -1060,10 +1098,67 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         }
         RG_STAMP(5);  // outputs stored
         // ---- fused auto-reset of finished envs (scenario.reset(); ~1 env in 70 per step)
+        RG_LATE(rc_raw);
+        RG_LATE(nx_tag);
+        // an env whose block holds exactly the episode that starts now copies it; any other runs the sampler
+        const bool have_next = ahead & (nx_tag == rc_raw);
         if (a.auto_reset && __any(env_ok & done)) {
             __syncthreads();  // the wave's state stores are issued before the resetting lanes rewrite them
-            RG_LATE(rc_raw);
-            reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done, rc_raw);
+            if (__any(env_ok & done & !have_next)) reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done & !have_next, rc_raw);
+            if (env_ok & done & have_next) {  // the same stores reset_group makes with commit = true
+                if (ag < N) {
+                    float *X = a.st.poses + eN * 3;
+                    X[ag] = nx_pose[0];
+                    X[N + ag] = nx_pose[1];
+                    X[2 * N + ag] = nx_pose[2];
+                    a.st.carry_dist[eN + ag] = 0.0f;
+                    if constexpr (SCN == RG_SCN_WAREHOUSE) a.st.loaded[eN + ag] = 0;
+                    if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
+                        a.st.load[eN + ag] = 0;
+                        if (ag < 4) a.st.messages[4 * e + ag] = 0;
+                    }
+                    if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+                        a.st.pixel_type[eN + ag] = 0;
+                        a.st.reached_goal[eN + ag] = 0;
+                    }
+                }
+                if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY || SCN == RG_SCN_SIMPLE) {
+                    const int P = q_P;
+                    const float *nb = q_nin + static_cast<size_t>(e) * q_nst + 3 * N;
+                    for (int i = ag; i < P; i += GW) {  // prey `ag` was prefetched; more than GW prey: the rest from the block
+                        float *pl = a.st.prey_loc + (static_cast<size_t>(e) * P + i) * 2;
+                        pl[0] = i == ag ? nx_a : nb[2 * i];
+                        pl[1] = i == ag ? nx_b : nb[2 * i + 1];
+                        if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
+                            a.st.prey_sensed[static_cast<size_t>(e) * P + i] = 0;
+                            a.st.prey_captured[static_cast<size_t>(e) * P + i] = 0;
+                        }
+                    }
+                } else if constexpr (SCN == RG_SCN_MATERIAL_TRANSPORT) {
+                    if (ag < 2) a.st.zone_load[2 * e + ag] = __builtin_bit_cast(int32_t, nx_a);
+                } else if constexpr (SCN == RG_SCN_ARCTIC_TRANSPORT) {
+                    uint32_t *gd = reinterpret_cast<uint32_t *>(a.st.grid + static_cast<size_t>(e) * 96);
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) gd[ag * 6 + t] = nx_grid[t];
+                    if (ag == 0) a.st.goal_col[e] = static_cast<int32_t>(nx_grid[6]);
+                }
+                if (ag == 0) {
+                    a.st.reset_count[e] = rc_raw + 1;
+                    a.st.episode_steps[e] = 0;
+                }
+            }
+        }
+        // ---- draw ahead: an env that goes on and whose block does not hold its next episode (consumed by the reset of
+        // an earlier launch, or never drawn) gets it now.  The block of an env that finished in THIS launch is left
+        // stale on purpose (it is redrawn in a later launch, off this launch's critical path).
+        // A wavefront that is already long -- a QP of one of its envs needed more than two sweeps, or a chunk was
+        // replayed -- leaves the draw to a later launch (an env that finishes before it happened runs the sampler as
+        // before): the draw must not lengthen the waves the launch is waiting for.
+        if (AHEAD && ahead && !(replayed | __any(max_sweeps > 2)) && __any(env_ok & !done & !have_next)) {
+            const bool need = env_ok & !done & !have_next;
+            __syncthreads();  // (LDS scratch of a reset above is free again)
+            reset_group<SCN, GW>(a, lds, e, g, ag, need, rc_raw, reset_dst_next(a, e));
+            if (need && ag == 0) a.st.next_episode[e] = rc_raw;
         }
         RG_STAMP(6);  // reset done
 #ifdef RG_STAMPS
@@ -1086,11 +1181,11 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ Lds<GW> lds;
     const int N = NT > 0 ? NT : a.p.n_agents;
     if constexpr (!ROLLOUT) {
-        step_once<SCN, GW, OBS_ONLY, NT>(a, lds, step_view(a, 0, N, a.p.obs_dim));
+        step_once<SCN, GW, OBS_ONLY, NT, true>(a, lds, step_view(a, 0, N, a.p.obs_dim));
     } else {
         for (int t = 0; t < a.num_steps; ++t) {
             if (t) __syncthreads();
-            step_once<SCN, GW, OBS_ONLY, NT>(a, lds, step_view(a, t, N, a.p.obs_dim));
+            step_once<SCN, GW, OBS_ONLY, NT, false>(a, lds, step_view(a, t, N, a.p.obs_dim));
         }
     }
 }

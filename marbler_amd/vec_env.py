@@ -80,6 +80,15 @@ class VecRobotariumEnv(object):
         self.done_return_sum = torch.zeros(E, dtype=f32, device=dev)
         self.done_count = torch.zeros(E, dtype=i32, device=dev)
         self.done_steps_sum = torch.zeros(E, dtype=i32, device=dev)
+        # ---- scratch of the lane-group kernel: every env's NEXT initial state, drawn ahead of time (derived data, not
+        # part of a snapshot).  Large batches run the thread-per-env kernel, which has no use for it.
+        self.next_init = self.next_episode = None
+        if E <= 65536:
+            stride = self.lib.rg_next_init_stride(C.byref(params))
+            if stride <= 0:
+                raise _lib.RobogymError("rg_next_init_stride failed: " + self.lib.rg_last_error().decode())
+            self.next_init = torch.zeros(E, stride, dtype=f32, device=dev)
+            self.next_episode = torch.full((E,), -1, dtype=i32, device=dev)
         # ---- step outputs (rg_step_io): views of ONE allocation, so a host-side consumer (the single-env
         # Wrapper) fetches everything a step returns with one device-to-host copy
         sizes = [("obs", E * N * D * 4), ("reward", E * N * 4), ("dist_travelled", E * N * 4), ("remaining", E * 4),
@@ -116,7 +125,9 @@ class VecRobotariumEnv(object):
             self.poses, self.carry_dist, self.episode_steps, self.reset_count, self.prey_loc, self.prey_sensed,
             self.prey_captured, self.loaded, self.load, self.zone_load, self.messages, self.grid, self.goal_col,
             self.pixel_type, self.reached_goal, self.ep_return,
-            self.done_return_sum, self.done_count, self.done_steps_sum)))
+            self.done_return_sum, self.done_count, self.done_steps_sum)),
+            self.next_init.data_ptr() if self.next_init is not None else None,
+            self.next_episode.data_ptr() if self.next_episode is not None else None)
         _lib.check(self.lib.rg_bind_state(self._h, C.byref(st)), "rg_bind_state")
         self._io = _lib.RgStepIO(self.obs.data_ptr(), self.reward.data_ptr(), self.done_u8.data_ptr(),
                                  self.dist_travelled.data_ptr(), self.violation.data_ptr(),
@@ -307,6 +318,8 @@ class VecRobotariumEnv(object):
         return sd
 
     def load_state_dict(self, sd):
+        if self.next_episode is not None:
+            self.next_episode.fill_(-1)     # drawn-ahead initial states belong to the state that is being replaced
         for k, v in sd.items():
             if k == "seed":
                 self.seed = int(v[0]) | (int(v[1]) << 32)

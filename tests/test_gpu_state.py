@@ -230,3 +230,34 @@ def test_env_on_a_non_current_device():
         o1, _, d1, _ = e1.step(a.to("cuda:1"))
         assert torch.cuda.current_device() == 0
         assert torch.equal(o0.cpu(), o1.cpu()) and torch.equal(d0.cpu(), d1.cpu())
+
+
+def test_drawn_ahead_resets_follow_a_seed_change(step_kernel):
+    """The lane-group kernel draws an env's next initial state ahead of time (rg_state.next_init).  Those blocks are
+    functions of (seed, env, episode): after `env.seed` changes they must not be used.  A: runs under seed 1, then
+    switches to seed 2; B: a fresh env with seed 2 loaded with A's state at the switch.  From there on A == B, bit for
+    bit, through many auto-resets."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    ov = {"predator": 3, "capture": 2, "n_agents": 5}
+    E = 512
+    a = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov, seed=1)
+    g = torch.Generator(device=a.device)
+    g.manual_seed(9)
+    acts = torch.randint(0, 5, (160, E, 5), generator=g, device=a.device, dtype=torch.int32)
+    a.reset()
+    for t in range(40):
+        a.step(acts[t])
+    if step_kernel == "group":
+        assert int((a.next_episode >= 0).sum()) > E // 2          # blocks are drawn ahead under seed 1
+    snap = a.state_dict()
+    a.seed = 2
+    snap["seed"] = torch.tensor([2, 0], dtype=torch.int64)
+    b = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov, seed=2)
+    b.load_state_dict(snap)
+    for t in range(40, 160):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        assert torch.equal(oa.view(torch.int32), ob.view(torch.int32)) and torch.equal(da, db), t
+        assert torch.equal(a.poses.view(torch.int32), b.poses.view(torch.int32)), t
+    assert int(a.done_count.sum()) > E and torch.equal(a.reset_count, b.reset_count)
