@@ -340,17 +340,16 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     // end of an earlier launch: fetched now with everything else, so that an env that finishes in this launch -- as a
     // rule the slowest wavefront's, a near-collision env -- starts its next episode with a handful of stores instead of
     // the sampler (Philox, Fisher-Yates through LDS: ~2 k cycles at the very end of the launch's critical path).
+    // Only the block's tag is fetched here (4 bytes per env); the block itself is fetched for the few envs that end
+    // (load_next below), early enough to hide its latency behind the epilogue.
     const bool ahead = AHEAD && (!OBS_ONLY) && q_nst > 0 && a.auto_reset;
     int nx_tag = -2;                               // episode the block was drawn for
     float nx_pose[3] = {0.0f, 0.0f, 0.0f};         // this lane's agent
     float nx_a = 0.0f, nx_b = 0.0f;                // PCP / Simple: prey `ag` (x, y); MaterialTransport: zone load `ag` (bits)
     uint32_t nx_grid[7] = {0, 0, 0, 0, 0, 0, 0};   // ArcticTransport: this lane's 6 terrain dwords + the goal column
-    if (env_ok) {
-        steps_raw = q_steps[e];
-        if (!OBS_ONLY && a.auto_reset) rc_raw = q_rc[e];
-        if (ahead) {
+    auto load_next = [&](bool want) {              // this lane's share of the env's drawn-ahead block
+        if (want) {
             const float *nb = q_nin + static_cast<size_t>(e) * q_nst;
-            nx_tag = q_nep[e];
             if (ag < N) {
                 nx_pose[0] = nb[ag];
                 nx_pose[1] = nb[N + ag];
@@ -370,6 +369,11 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                 nx_grid[6] = gb[24];
             }
         }
+    };
+    if (env_ok) {
+        steps_raw = q_steps[e];
+        if (!OBS_ONLY && a.auto_reset) rc_raw = q_rc[e];
+        if (ahead) nx_tag = q_nep[e];
         if (stats && ag == 0) {
             st_ret = q_ret[e];
             st_sum = q_sum[e];
@@ -671,6 +675,13 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     float reward = 0.0f;
     RG_LATE(steps_raw);
     const int steps = steps_raw + (OBS_ONLY ? 0 : 1);
+    // an env that ends by a violation or by the step limit (all but a few endings) is known to end already: its
+    // drawn-ahead block is fetched now, behind the epilogue
+    RG_LATE(rc_raw);
+    RG_LATE(nx_tag);
+    const bool have_next = ahead & (nx_tag == rc_raw);  // the block holds exactly the episode that would start now
+    const bool next_early = env_ok & have_next & ((viol != 0) | (steps > p.max_episode_steps));
+    if constexpr (AHEAD) load_next(next_early);
 
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = q_P;
@@ -1098,12 +1109,10 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         }
         RG_STAMP(5);  // outputs stored
         // ---- fused auto-reset of finished envs (scenario.reset(); ~1 env in 70 per step)
-        RG_LATE(rc_raw);
-        RG_LATE(nx_tag);
         // an env whose block holds exactly the episode that starts now copies it; any other runs the sampler
-        const bool have_next = ahead & (nx_tag == rc_raw);
         if (a.auto_reset && __any(env_ok & done)) {
             __syncthreads();  // the wave's state stores are issued before the resetting lanes rewrite them
+            if constexpr (AHEAD) load_next(env_ok & done & have_next & !next_early);  // ended some other way: fetched late
             if (__any(env_ok & done & !have_next)) reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done & !have_next, rc_raw);
             if (env_ok & done & have_next) {  // the same stores reset_group makes with commit = true
                 if (ag < N) {
