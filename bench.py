@@ -388,7 +388,8 @@ def main():
 
     rank, world, local = rgdist.init_from_env(backend=args.dist_backend, device_index=0 if args.share_gpu else None)
     collective = None
-    if world > 1:
+    grouped = dist.is_initialized()     # world > 1, or one rank with RG_FORCE_PROCESS_GROUP=1 (the RCCL path on a one-GPU box)
+    if grouped:
         # every rank reports in: an all_gather of the rank ids over the backend the run uses
         cdev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", local)
         me = torch.tensor([rank], dtype=torch.int64, device=cdev)
@@ -403,7 +404,7 @@ def main():
             sys.exit(3)
     if args.dry_run:
         return dry_run(args, rank, world, collective)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if grouped else 0)
     torch.cuda.set_device(dev)
     E = args.envs_per_gpu
     K, W = args.steps, args.warmup
@@ -413,7 +414,7 @@ def main():
         {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}
     # rank 0 reads the YAML; every rank gets the parameter block by RCCL broadcast
     params = make_params(args.scenario, load_config(args.scenario, overrides=overrides)) if rank == 0 else None
-    if world > 1:
+    if grouped:
         if rank != 0:
             params = make_params(args.scenario, load_config(args.scenario, overrides=overrides))  # shape only
         params = rgdist.broadcast_params(params, src=0, device=dev)
@@ -431,7 +432,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -453,7 +454,7 @@ def main():
     barrier()
     assert rc == 0
     gpu_ms_total = ev0.elapsed_time(ev1)
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=rgdist.collective_device(dev), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -528,7 +529,7 @@ def main():
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

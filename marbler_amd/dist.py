@@ -22,7 +22,10 @@ def init_from_env(backend=None, device_index=None):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if device_index is not None:
         local = int(device_index)
-    if world > 1 and not dist.is_initialized():
+    # RG_FORCE_PROCESS_GROUP=1: a process group even for one rank, so that a one-GPU box runs the RCCL code path of the
+    # N > 1 job (parameter broadcast, statistics gather, barrier, max-reduction) end to end (tests/test_gpu_dist.py)
+    force = os.environ.get("RG_FORCE_PROCESS_GROUP") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -53,7 +56,7 @@ def shard(total_envs, rank, world):
 
 def broadcast_params(params, src=0, device=None):
     """Rank `src` sends its rg_scenario_params block (< 1 KB); every rank returns a copy of it."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return params
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -74,7 +77,7 @@ def gather_episode_stats(done_return_sum, done_count, done_steps_sum, dst=0):
     equal up to one env; shorter shards are padded).  Returns (returns [E_total] f32, counts i64, steps i64) on
     `dst`, None elsewhere.  With no process group: the inputs.
     RCCL (nccl backend) has a true gather to one root; gloo on CPU does too."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return done_return_sum, done_count.to(torch.int64), done_steps_sum.to(torch.int64)
     world, rank = dist.get_world_size(), dist.get_rank()
     cdev = collective_device(done_return_sum.device)
