@@ -145,6 +145,15 @@ typedef struct rg_step_io {
     uint8_t *violation;    /* [E]     info['message'] as RG_VIOL_* */
     int32_t *remaining;    /* [E]     info['remaining'], -1 when the reference omits the key */
     int32_t *qp_sweeps;    /* [E] or NULL: diagnostic, max barrier-QP sweeps in this step */
+    /* Optional (elapsed NULL = off): what EPyMARL's gymma wrapper puts around the env -- gym's TimeLimit and the
+     * reductions float(sum(reward_n)), all(done_n) (README.md:25-28 of the reference; the wrapper itself is external) --
+     * computed by the same launch instead of a dozen elementwise launches around it. */
+    int32_t *elapsed;      /* [E] in/out (state, not per step): steps since the env's last (re)start, TimeLimit's counter */
+    uint8_t *truncated;    /* [E] out: 1 = the time limit, not the scenario, ended the episode in this step (info['TimeLimit.truncated']) */
+    uint8_t *ended;        /* [E] out: done | truncated -- what gymma returns as `terminated`; with auto_reset such an env is
+                              reset in the same launch, and a truncated episode is booked in the statistics like a finished one */
+    float *reward_sum;     /* [E] out: the sum of the agents' rewards in agent order */
+    int32_t time_limit;    /* TimeLimit's max_episode_steps (> 0) */
 } rg_step_io;
 
 typedef struct rg_handle rg_handle;

@@ -67,7 +67,9 @@ class RgState(C.Structure):
 class RgStepIO(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
                 ("dist_travelled", C.c_void_p), ("violation", C.c_void_p), ("remaining", C.c_void_p),
-                ("qp_sweeps", C.c_void_p)]
+                ("qp_sweeps", C.c_void_p),
+                ("elapsed", C.c_void_p), ("truncated", C.c_void_p), ("ended", C.c_void_p), ("reward_sum", C.c_void_p),
+                ("time_limit", C.c_int32)]
 
 
 class RgActorWeights(C.Structure):

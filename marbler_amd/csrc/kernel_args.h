@@ -107,6 +107,11 @@ __host__ __device__ inline StepView step_view(const KernelArgs &a, int k, int n_
     v.io.violation = a.io.violation ? a.io.violation + e : nullptr;
     v.io.remaining = a.io.remaining ? a.io.remaining + e : nullptr;
     v.io.qp_sweeps = a.io.qp_sweeps ? a.io.qp_sweeps + e : nullptr;
+    v.io.elapsed = a.io.elapsed;  // state: the same counter for every step of a multi-step launch
+    v.io.truncated = a.io.truncated ? a.io.truncated + e : nullptr;
+    v.io.ended = a.io.ended ? a.io.ended + e : nullptr;
+    v.io.reward_sum = a.io.reward_sum ? a.io.reward_sum + e : nullptr;
+    v.io.time_limit = a.io.time_limit;
     return v;
 }
 // thread-per-env step kernel (robogym_tpe.hip): same results, chosen by the host for large batches

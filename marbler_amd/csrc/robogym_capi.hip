@@ -238,6 +238,17 @@ static int sync_seed(rg_handle *h, uint64_t seed) {
     return 0;
 }
 
+static int check_io(const rg_step_io *io) {
+    if (!io->obs || !io->reward || !io->done || !io->dist_travelled || !io->violation || !io->remaining)
+        return fail(-24, "every rg_step_io array except qp_sweeps and the gymma block is required");
+    if (reinterpret_cast<uintptr_t>(io->obs) & 15u) return fail(-26, "obs must be 16-byte aligned");
+    if (io->elapsed) {
+        if (!io->truncated || !io->ended || !io->reward_sum) return fail(-24, "gymma block: elapsed needs truncated, ended and reward_sum");
+        if (io->time_limit < 1) return fail(-29, "gymma block: time_limit must be > 0");
+    }
+    return 0;
+}
+
 static int launched(hipError_t err) {
     if (err != hipSuccess) return fail(-30, "kernel launch failed: %s", hipGetErrorString(err));
     return 0;
@@ -262,9 +273,7 @@ int rg_step(rg_handle *h, const int32_t *actions, const rg_step_io *io, int32_t 
     rg::KernelArgs a;
     if (int rc = fill_args(h, a)) return rc;
     if (!actions || !io) return fail(-23, "actions or io is NULL");
-    if (!io->obs || !io->reward || !io->done || !io->dist_travelled || !io->violation || !io->remaining)
-        return fail(-24, "every rg_step_io array except qp_sweeps is required");
-    if (reinterpret_cast<uintptr_t>(io->obs) & 15u) return fail(-26, "obs must be 16-byte aligned");
+    if (int rc = check_io(io)) return rc;
     a.actions = actions;
     a.io = *io;
     a.auto_reset = auto_reset;
@@ -280,9 +289,7 @@ int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg
     if (int rc = fill_args(h, a)) return rc;
     if (!actions || !io) return fail(-23, "actions or io is NULL");
     if (num_steps < 1) return fail(-27, "num_steps < 1");
-    if (!io->obs || !io->reward || !io->done || !io->dist_travelled || !io->violation || !io->remaining)
-        return fail(-24, "every rg_step_io array except qp_sweeps is required");
-    if (reinterpret_cast<uintptr_t>(io->obs) & 15u) return fail(-26, "obs must be 16-byte aligned");
+    if (int rc = check_io(io)) return rc;
     // every step's [E][N][D] slice must keep the 16-byte alignment of the block stores
     if ((static_cast<size_t>(h->num_envs) * h->params.n_agents * h->params.obs_dim) & 3u)
         return fail(-26, "E*N*D must be a multiple of 4 for rg_rollout");

@@ -279,12 +279,14 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     // before the first controller (tools/stamp_probe.py).  The empty asm makes all of them live here: one trip.
     const float *q_poses = a.st.poses, *q_carry = a.st.carry_dist, *q_ret = a.st.ep_return, *q_sum = a.st.done_return_sum;
     const int32_t *q_steps = a.st.episode_steps, *q_act = sv.actions, *q_cnt = a.st.done_count, *q_stp = a.st.done_steps_sum;
+    int32_t *q_el = OBS_ONLY ? nullptr : sv.io.elapsed;  // gymma block (gym TimeLimit's counter), NULL = off
+    const int q_tl = sv.io.time_limit;
     const int32_t *q_rc = a.st.reset_count, *q_nep = AHEAD ? a.st.next_episode : nullptr;
     const float *q_nin = AHEAD ? a.st.next_init : nullptr;
     const int q_nst = AHEAD ? a.next_stride : 0;
     const int q_E = a.E, q_epw = a.envs_per_wave, q_P = p.num_prey, q_N = p.n_agents, q_G = gridDim.x;
     asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp),
-                 "s"(q_E), "s"(q_epw), "s"(q_P), "s"(q_N), "s"(q_G), "s"(q_rc));
+                 "s"(q_E), "s"(q_epw), "s"(q_P), "s"(q_N), "s"(q_G), "s"(q_rc), "s"(q_el), "s"(q_tl));
     if constexpr (AHEAD) asm volatile("" ::"s"(q_nep), "s"(q_nin), "s"(q_nst));
     const float *q_prey = a.st.prey_loc;
     const uint8_t *q_sen = a.st.prey_sensed, *q_cap = a.st.prey_captured, *q_loaded = a.st.loaded, *q_grid = a.st.grid;
@@ -370,9 +372,11 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             }
         }
     };
+    int el_raw = 0;
     if (env_ok) {
         steps_raw = q_steps[e];
         if (!OBS_ONLY && a.auto_reset) rc_raw = q_rc[e];
+        if (q_el) el_raw = q_el[e];
         if (ahead) nx_tag = q_nep[e];
         if (stats && ag == 0) {
             st_ret = q_ret[e];
@@ -1068,9 +1072,17 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 
     RG_STAMP(4);  // scenario epilogue computed
     if constexpr (!OBS_ONLY) {
-        // sum of the agents' rewards in agent order (only read when shared_reward == 0)
+        // gym's TimeLimit on top of the scenario (gymma block of rg_step_io): the limit ends an episode the scenario did not
+        const bool gym = q_el != nullptr;
+        bool trunc = false;
+        if (gym) {
+            RG_LATE(el_raw);
+            trunc = env_ok & !done & (el_raw + 1 >= q_tl);
+        }
+        const bool ended = done | trunc;
+        // sum of the agents' rewards in agent order (read when shared_reward == 0, and by the gymma block)
         float rsum = 0.0f;
-        if (stats && !p.shared_reward) {
+        if ((stats && !p.shared_reward) || gym) {
             __syncthreads();
             lds.ax[lane] = lane_ok ? reward : 0.0f;
             __syncthreads();
@@ -1093,7 +1105,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     RG_LATE(st_cnt);
                     RG_LATE(st_steps);
                     float ret = st_ret + (p.shared_reward ? reward : rsum);
-                    if (done) {
+                    if (ended) {  // a truncated episode counts like a finished one (run_env counts them, misc.py:186-206)
                         a.st.done_return_sum[e] = st_sum + ret;
                         a.st.done_count[e] = st_cnt + 1;
                         a.st.done_steps_sum[e] = st_steps + steps;
@@ -1102,6 +1114,12 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     a.st.ep_return[e] = ret;
                 }
                 sv.io.done[e] = done ? 1 : 0;
+                if (gym) {
+                    q_el[e] = ended ? 0 : el_raw + 1;
+                    sv.io.truncated[e] = trunc ? 1 : 0;
+                    sv.io.ended[e] = ended ? 1 : 0;
+                    sv.io.reward_sum[e] = rsum;
+                }
                 sv.io.violation[e] = static_cast<uint8_t>(viol);
                 sv.io.remaining[e] = remaining;
                 if (sv.io.qp_sweeps) sv.io.qp_sweeps[e] = max_sweeps;
@@ -1110,11 +1128,11 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         RG_STAMP(5);  // outputs stored
         // ---- fused auto-reset of finished envs (scenario.reset(); ~1 env in 70 per step)
         // an env whose block holds exactly the episode that starts now copies it; any other runs the sampler
-        if (a.auto_reset && __any(env_ok & done)) {
+        if (a.auto_reset && __any(env_ok & ended)) {
             __syncthreads();  // the wave's state stores are issued before the resetting lanes rewrite them
-            if constexpr (AHEAD) load_next(env_ok & done & have_next & !next_early);  // ended some other way: fetched late
-            if (__any(env_ok & done & !have_next)) reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & done & !have_next, rc_raw);
-            if (env_ok & done & have_next) {  // the same stores reset_group makes with commit = true
+            if constexpr (AHEAD) load_next(env_ok & ended & have_next & !next_early);  // ended some other way: fetched late
+            if (__any(env_ok & ended & !have_next)) reset_group<SCN, GW>(a, lds, e, g, ag, env_ok & ended & !have_next, rc_raw);
+            if (env_ok & ended & have_next) {  // the same stores reset_group makes with commit = true
                 if (ag < N) {
                     float *X = a.st.poses + eN * 3;
                     X[ag] = nx_pose[0];
@@ -1163,8 +1181,8 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         // A wavefront that is already long -- a QP of one of its envs needed more than two sweeps, or a chunk was
         // replayed -- leaves the draw to a later launch (an env that finishes before it happened runs the sampler as
         // before): the draw must not lengthen the waves the launch is waiting for.
-        if (AHEAD && ahead && !(replayed | __any(max_sweeps > 2)) && __any(env_ok & !done & !have_next)) {
-            const bool need = env_ok & !done & !have_next;
+        if (AHEAD && ahead && !(replayed | __any(max_sweeps > 2)) && __any(env_ok & !ended & !have_next)) {
+            const bool need = env_ok & !ended & !have_next;
             __syncthreads();  // (LDS scratch of a reset above is free again)
             reset_group<SCN, GW>(a, lds, e, g, ag, need, rc_raw, reset_dst_next(a, e));
             if (need && ag == 0) a.st.next_episode[e] = rc_raw;

@@ -286,6 +286,8 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     }
     int steps_raw = q_steps[e];
     if (a.auto_reset) rc_raw = a.st.reset_count[e];  // for the fused reset, should this env finish
+    int32_t *q_el = sv.io.elapsed;                    // gymma block (gym TimeLimit's counter), NULL = off
+    int el_raw = q_el ? q_el[e] : 0;
     const bool stats = q_ret != nullptr;
     float st_ret = 0.0f, st_sum = 0.0f;
     int st_cnt = 0, st_steps = 0;
@@ -797,6 +799,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     }
 
     // ---- stores
+    bool trunc = false;
     {
         float *X = a.st.poses + eN * 3;
         float rsum = 0.0f;
@@ -815,9 +818,18 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             rsum = rsum + reward[i];
         }
         a.st.episode_steps[e] = steps;
+        // gym's TimeLimit on top of the scenario (gymma block of rg_step_io)
+        if (q_el) {
+            RG_LATE(el_raw);
+            trunc = !done & (el_raw + 1 >= sv.io.time_limit);
+            q_el[e] = (done | trunc) ? 0 : el_raw + 1;
+            sv.io.truncated[e] = trunc ? 1 : 0;
+            sv.io.ended[e] = (done | trunc) ? 1 : 0;
+            sv.io.reward_sum[e] = rsum;
+        }
         if (stats) {  // misc.py:178-185
             float ret = st_ret + (p.shared_reward ? reward[0] : rsum);
-            if (done) {
+            if (done | trunc) {  // a truncated episode counts like a finished one
                 a.st.done_return_sum[e] = st_sum + ret;
                 a.st.done_count[e] = st_cnt + 1;
                 a.st.done_steps_sum[e] = st_steps + steps;
@@ -833,7 +845,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #endif
         if (sv.io.qp_sweeps) sv.io.qp_sweeps[e] = max_sweeps;
     }
-    return done;
+    return done | trunc;
 }
 
 // ------------------------------------------------------------------ the step kernel

@@ -38,7 +38,11 @@ class GymmaVecEnv(object):
     """E envs behind gymma's method names; everything is a device tensor with a leading E axis."""
 
     def __init__(self, key, num_envs, time_limit, config_path=None, overrides=None, device="cuda:0", seed=0,
-                 env_offset=0):
+                 env_offset=0, fused=True):
+        """fused: gym's TimeLimit and the gymma reductions run inside the env's step launch (VecRobotariumEnv.
+        enable_time_limit): step() is ONE launch.  fused=False composes them from torch ops around the step (a dozen
+        launches; kept as the readable statement of the contract and as the check of the fused path)."""
+        self.fused = bool(fused)
         self.scenario = scenario_from_key(key)
         self.env = VecRobotariumEnv(self.scenario, num_envs, config_path=config_path, overrides=overrides,
                                     device=device, seed=seed, env_offset=env_offset, auto_reset=True,
@@ -53,11 +57,15 @@ class GymmaVecEnv(object):
         # gym's TimeLimit can only fire if it is not longer than the scenario's own horizon
         # (episodes end at step max_episode_steps + 1 at the latest): otherwise nothing to do per step
         self._can_truncate = self.episode_limit <= int(self.env.params.max_episode_steps) + 1
+        self._ended = None
+        if self.fused:
+            self.env.enable_time_limit(self.episode_limit)
 
     # -- gymma surface, batched
     def reset(self):
         self._obs = self.env.reset()
         self._elapsed.zero_()
+        self._ended = None
         return self.get_obs(), self.get_state()
 
     def step(self, actions):
@@ -65,6 +73,11 @@ class GymmaVecEnv(object):
         Envs that terminate (scenario rule or time limit) start a new episode; their next observation
         is the reset observation (zeros, as the reference returns from reset())."""
         obs, reward, done, info = self.env.step(actions)
+        if self.fused:      # everything below happened inside that one launch
+            self._obs, self._ended = None, self.env.ended
+            out = dict(info)
+            out["TimeLimit.truncated"] = self.env.truncated
+            return self.env.reward_sum, self.env.ended, out
         self._elapsed += 1
         truncated = (self._elapsed >= self.episode_limit) & ~done          # gym TimeLimit
         ended = done | truncated
@@ -81,16 +94,18 @@ class GymmaVecEnv(object):
         return reward.sum(dim=1), ended, out
 
     def get_obs(self):
+        if self._obs is None:   # fused step: the next observation of an env that just ended is its reset observation (zeros)
+            self._obs = torch.where(self._ended[:, None, None], 0.0, self.env.obs)
         return self._obs
 
     def get_obs_agent(self, agent_id):
-        return self._obs[:, agent_id]
+        return self.get_obs()[:, agent_id]
 
     def get_obs_size(self):
         return self.obs_size
 
     def get_state(self):
-        return self._obs.reshape(self.E, -1)
+        return self.get_obs().reshape(self.E, -1)
 
     def get_state_size(self):
         return self.n_agents * self.obs_size
@@ -132,7 +147,7 @@ class GymmaEnv(object):
     """One env with EPyMARL's Python-level types (lists of numpy arrays, floats, bools)."""
 
     def __init__(self, key, time_limit, pretrained_wrapper=None, seed=None, device="cuda:0", **kwargs):
-        self._v = GymmaVecEnv(key, 1, time_limit, device=device, seed=seed, overrides=kwargs or None)
+        self._v = GymmaVecEnv(key, 1, time_limit, device=device, seed=seed, overrides=kwargs or None, fused=False)
         # auto-reset is the runner's job in EPyMARL: keep the terminal state until reset() is called
         self._v.env.auto_reset = False
         self.n_agents = self._v.n_agents

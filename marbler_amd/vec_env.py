@@ -135,6 +135,8 @@ class VecRobotariumEnv(object):
                                  self.qp_sweeps.data_ptr() if self.qp_sweeps is not None else None)
         self._io_ref = C.byref(self._io)
         self._actions_i32 = torch.zeros(E, N, dtype=i32, device=dev)
+        self.time_limit = 0
+        self.elapsed = self.truncated = self.ended = self.reward_sum = None
 
     # ------------------------------------------------------------------ reference surface
     @property
@@ -169,6 +171,11 @@ class VecRobotariumEnv(object):
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mptr = mask.data_ptr()
         _lib.check(self.lib.rg_reset(self._h, mptr, self.seed, _lib.RESET_BOOK_EPISODE if book_episode else 0), "rg_reset")
+        if self.elapsed is not None:                 # a reset env's TimeLimit counter restarts
+            if mask is None:
+                self.elapsed.zero_()
+            else:
+                self.elapsed.masked_fill_(mask.bool(), 0)
         if reference_rng is not None:
             self._upload_reference_reset(mask, reference_rng, py_random)
         if self.reference_reset_obs:
@@ -202,6 +209,24 @@ class VecRobotariumEnv(object):
         if "grid" in draws[0]:
             put(self.grid, "grid", np.uint8)
             self.goal_col[ix] = torch.as_tensor([d["goal_col"] for d in draws], dtype=torch.int32, device=self.device)
+
+    def enable_time_limit(self, time_limit):
+        """gym's TimeLimit and EPyMARL's gymma reductions inside the step launch (rg_step_io's gymma block): every step()
+        then also fills `reward_sum` [E] f32 (sum over agents), `truncated` [E] bool (the limit, not the scenario, ended
+        the episode), `ended` [E] bool (done | truncated); an ended env restarts in the same launch (auto_reset) and a
+        truncated episode is booked in the episode statistics.  `elapsed` [E] i32 is TimeLimit's counter (state)."""
+        E, dev = self.E, self.device
+        self.time_limit = int(time_limit)
+        if self.time_limit < 1:
+            raise ValueError("time_limit must be > 0")
+        self.elapsed = torch.zeros(E, dtype=torch.int32, device=dev)
+        self._trunc_u8 = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self._ended_u8 = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self.truncated, self.ended = self._trunc_u8.view(torch.bool), self._ended_u8.view(torch.bool)
+        self.reward_sum = torch.zeros(E, dtype=torch.float32, device=dev)
+        self._io.elapsed, self._io.truncated = self.elapsed.data_ptr(), self._trunc_u8.data_ptr()
+        self._io.ended, self._io.reward_sum = self._ended_u8.data_ptr(), self.reward_sum.data_ptr()
+        self._io.time_limit = self.time_limit
 
     def step(self, actions):
         """actions: int tensor [E,N] on the device (int32 is used as is; other int dtypes are

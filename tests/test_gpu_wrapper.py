@@ -168,3 +168,46 @@ def test_gymma_env_reduces_the_reference_vectors_like_epymarl(name):
         assert np.array_equal(env.get_state(), obs.reshape(-1))
         assert info.get("message") == MSG[int(g["viol"][t])]
     env.close()
+
+
+@pytest.mark.parametrize("kernel", ["group", "tpe"])
+@pytest.mark.parametrize("key,ov,n_act,limit", [
+    ("robotarium_gym:PredatorCapturePrey-v0", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 9),
+    ("robotarium_gym:Warehouse-v0", {"n_agents": 8}, 5, 1000),
+    ("robotarium_gym:MaterialTransport-v0", {}, 20, 7)])
+def test_fused_time_limit_equals_the_composed_gymma_step(kernel, key, ov, n_act, limit, monkeypatch):
+    """gym's TimeLimit and the gymma reductions inside the step launch (rg_step_io's gymma block) against the same
+    contract composed from torch ops around the plain step: rewards, terminated / truncated flags, the observations a
+    consumer sees next, the episode statistics and the env state, step after step through truncations and resets."""
+    import torch
+    from marbler_amd.gymma import GymmaVecEnv
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
+    E = 256
+    a = GymmaVecEnv(key, E, time_limit=limit, overrides=ov, seed=5, fused=True)
+    b = GymmaVecEnv(key, E, time_limit=limit, overrides=ov, seed=5, fused=False)
+    assert a.env.time_limit == limit and b.env.time_limit == 0
+    a.reset()
+    b.reset()
+    g = torch.Generator(device=a.env.device)
+    g.manual_seed(3)
+    n_trunc = n_done = 0
+    for t in range(90):
+        act = torch.randint(0, n_act, (E, a.n_agents), generator=g, device=a.env.device, dtype=torch.int32)
+        ra, ta, ia = a.step(act)
+        rb, tb, ib = b.step(act)
+        assert torch.equal(ta, tb) and torch.equal(ia["TimeLimit.truncated"], ib["TimeLimit.truncated"]), t
+        assert torch.allclose(ra, rb, rtol=0, atol=1e-5), t
+        assert torch.equal(a.get_obs().view(torch.int32), b.get_obs().view(torch.int32)), t
+        assert torch.equal(a.get_state(), a.get_obs().reshape(E, -1))
+        for k in ("violation", "remaining", "dist_travelled"):
+            assert torch.equal(ia[k], ib[k]), (t, k)
+        assert torch.equal(a.env.poses.view(torch.int32), b.env.poses.view(torch.int32)), t
+        assert torch.equal(a.env.episode_steps, b.env.episode_steps) and torch.equal(a.env.reset_count, b.env.reset_count)
+        n_trunc += int(ia["TimeLimit.truncated"].sum())
+        n_done += int(ta.sum())
+    sa, sb = a.get_stats(), b.get_stats()
+    assert sa["episodes"] == sb["episodes"] == n_done and sa["steps"] == sb["steps"]
+    assert abs(sa["return_sum"] - sb["return_sum"]) < 1e-3 * max(1.0, abs(sb["return_sum"]))
+    assert n_done > E // 2 and (n_trunc > E if limit < 50 else n_trunc == 0)
+    a.close()
+    b.close()
