@@ -339,6 +339,8 @@ class VecRobotariumEnv(object):
     def state_dict(self):
         """Snapshot of the env state (cloned tensors) + the sampler key, loadable with load_state_dict()."""
         sd = {k: getattr(self, k).clone() for k in self.STATE_KEYS}
+        if self.elapsed is not None:
+            sd["elapsed"] = self.elapsed.clone()     # gym TimeLimit's counter (enable_time_limit)
         sd["seed"] = torch.tensor([self.seed & 0xFFFFFFFF, self.seed >> 32], dtype=torch.int64)
         return sd
 

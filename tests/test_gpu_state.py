@@ -48,6 +48,33 @@ def test_snapshot_restores_and_continues_bit_identically(scenario, ov, n_act, st
     assert int(b.done_count.sum()) > int(snap["done_count"].sum())  # episodes ended, and were reset, after the restore
 
 
+def test_snapshot_of_a_time_limited_env_keeps_the_time_limit_counter(step_kernel):
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    ov = {"predator": 3, "capture": 2, "n_agents": 5}
+    a = VecRobotariumEnv("PredatorCapturePrey", 128, overrides=ov, seed=3)
+    a.enable_time_limit(11)
+    acts = torch.randint(0, 5, (60, 128, 5), device=a.device, dtype=torch.int32)
+    a.reset()
+    for t in range(17):
+        a.step(acts[t])
+    snap = {k: v.cpu() for k, v in a.state_dict().items()}
+    assert "elapsed" in snap and int(snap["elapsed"].max()) > 0
+    ends_a = []
+    for t in range(17, 60):
+        a.step(acts[t])
+        ends_a.append((a.ended.clone(), a.truncated.clone(), a.reward_sum.clone()))
+    b = VecRobotariumEnv("PredatorCapturePrey", 128, overrides=ov, seed=77)
+    b.enable_time_limit(11)
+    b.load_state_dict(snap)
+    for t in range(17, 60):
+        b.step(acts[t])
+        e, tr, rs = ends_a[t - 17]
+        assert torch.equal(b.ended, e) and torch.equal(b.truncated, tr) and torch.equal(b.reward_sum.view(torch.int32), rs.view(torch.int32)), t
+    assert torch.equal(a.elapsed, b.elapsed) and torch.equal(a.poses.view(torch.int32), b.poses.view(torch.int32))
+    assert int(sum(int(x[1].sum()) for x in ends_a)) > 0       # the limit did fire
+
+
 def test_explicit_reset_restarts_the_running_return_and_can_book_the_episode(step_kernel):
     import torch
     from marbler_amd import VecRobotariumEnv
