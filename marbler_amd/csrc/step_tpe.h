@@ -284,19 +284,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = q_carry[eN + i];  // dist incl. the pending sub-step (first used at the period end)
     }
-    int steps_raw = q_steps[e];
-    if (a.auto_reset) rc_raw = a.st.reset_count[e];  // for the fused reset, should this env finish
-    int32_t *q_el = sv.io.elapsed;                    // gymma block (gym TimeLimit's counter), NULL = off
-    int el_raw = q_el ? q_el[e] : 0;
+    // (step counter, reset counter and statistics words are fetched in the epilogue, where they are used: this kernel
+    // has no register to spare -- a value more live through the step costs its second wave per SIMD -- and the second
+    // wave hides the latency)
+
     const bool stats = q_ret != nullptr;
-    float st_ret = 0.0f, st_sum = 0.0f;
-    int st_cnt = 0, st_steps = 0;
-    if (stats) {
-        st_ret = q_ret[e];
-        st_sum = q_sum[e];
-        st_cnt = q_cnt[e];
-        st_steps = q_stp[e];
-    }
 
     // ---- a1 goal generation
     float gx[N], gy[N];
@@ -478,8 +470,8 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     bool done = false;
     int remaining = -1;
     float reward[N];
-    RG_LATE(steps_raw);
-    const int steps = steps_raw + 1;
+    const int steps = q_steps[e] + 1;
+    if (a.auto_reset) rc_raw = a.st.reset_count[e];  // for the fused reset, should this env finish
 
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
@@ -803,10 +795,14 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     {
         float *X = a.st.poses + eN * 3;
         float rsum = 0.0f;
-        RG_LATE(st_ret);
-        RG_LATE(st_sum);
-        RG_LATE(st_cnt);
-        RG_LATE(st_steps);
+        float st_ret = 0.0f, st_sum = 0.0f;
+        int st_cnt = 0, st_steps = 0;
+        if (stats) {
+            st_ret = q_ret[e];
+            st_sum = q_sum[e];
+            st_cnt = q_cnt[e];
+            st_steps = q_stp[e];
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             X[i] = x[i];
@@ -819,8 +815,10 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         }
         a.st.episode_steps[e] = steps;
         // gym's TimeLimit on top of the scenario (gymma block of rg_step_io)
-        if (q_el) {
-            RG_LATE(el_raw);
+        // (the counter is fetched here, not with the state: this kernel has no register to spare -- one more value live
+        // through the step costs its second wave per SIMD)
+        if (int32_t *q_el = sv.io.elapsed) {
+            const int el_raw = q_el[e];
             trunc = !done & (el_raw + 1 >= sv.io.time_limit);
             q_el[e] = (done | trunc) ? 0 : el_raw + 1;
             sv.io.truncated[e] = trunc ? 1 : 0;
