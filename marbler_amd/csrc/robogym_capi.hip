@@ -289,6 +289,7 @@ int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg
     if (int rc = fill_args(h, a)) return rc;
     if (!actions || !io) return fail(-23, "actions or io is NULL");
     if (num_steps < 1) return fail(-27, "num_steps < 1");
+    if (io->elapsed) return fail(-29, "the gymma block of rg_step_io belongs to rg_step (one launch per step)");
     if (int rc = check_io(io)) return rc;
     // every step's [E][N][D] slice must keep the 16-byte alignment of the block stores
     if ((static_cast<size_t>(h->num_envs) * h->params.n_agents * h->params.obs_dim) & 3u)

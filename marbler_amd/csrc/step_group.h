@@ -264,7 +264,9 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
 // action and output arrays.
 // AHEAD: use (and keep filled) the drawn-ahead initial states of rg_state.next_init.  Off in the multi-step launch: there
 // the launch costs the MEAN wavefront, and drawing ahead moves the sampler's work without removing any.
-template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD>
+// GYM: the gymma block of rg_step_io (gym's TimeLimit + reductions) is compiled in.  Its own instantiations (generic agent
+// count, single-step launch): the benchmark kernels carry none of it.
+template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD, bool GYM>
 __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, const StepView &sv) {
     constexpr int EPW = WAVE / GW;  // envs per wave
 #ifdef RG_STAMPS
@@ -279,14 +281,15 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     // before the first controller (tools/stamp_probe.py).  The empty asm makes all of them live here: one trip.
     const float *q_poses = a.st.poses, *q_carry = a.st.carry_dist, *q_ret = a.st.ep_return, *q_sum = a.st.done_return_sum;
     const int32_t *q_steps = a.st.episode_steps, *q_act = sv.actions, *q_cnt = a.st.done_count, *q_stp = a.st.done_steps_sum;
-    int32_t *q_el = OBS_ONLY ? nullptr : sv.io.elapsed;  // gymma block (gym TimeLimit's counter), NULL = off
-    const int q_tl = sv.io.time_limit;
+    int32_t *q_el = GYM ? sv.io.elapsed : nullptr;  // gymma block (gym TimeLimit's counter)
+    const int q_tl = GYM ? sv.io.time_limit : 0;
     const int32_t *q_rc = a.st.reset_count, *q_nep = AHEAD ? a.st.next_episode : nullptr;
     const float *q_nin = AHEAD ? a.st.next_init : nullptr;
     const int q_nst = AHEAD ? a.next_stride : 0;
     const int q_E = a.E, q_epw = a.envs_per_wave, q_P = p.num_prey, q_N = p.n_agents, q_G = gridDim.x;
     asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp),
-                 "s"(q_E), "s"(q_epw), "s"(q_P), "s"(q_N), "s"(q_G), "s"(q_rc), "s"(q_el), "s"(q_tl));
+                 "s"(q_E), "s"(q_epw), "s"(q_P), "s"(q_N), "s"(q_G), "s"(q_rc));
+    if constexpr (GYM) asm volatile("" ::"s"(q_el), "s"(q_tl));
     if constexpr (AHEAD) asm volatile("" ::"s"(q_nep), "s"(q_nin), "s"(q_nst));
     const float *q_prey = a.st.prey_loc;
     const uint8_t *q_sen = a.st.prey_sensed, *q_cap = a.st.prey_captured, *q_loaded = a.st.loaded, *q_grid = a.st.grid;
@@ -376,7 +379,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     if (env_ok) {
         steps_raw = q_steps[e];
         if (!OBS_ONLY && a.auto_reset) rc_raw = q_rc[e];
-        if (q_el) el_raw = q_el[e];
+        if constexpr (GYM) el_raw = q_el[e];
         if (ahead) nx_tag = q_nep[e];
         if (stats && ag == 0) {
             st_ret = q_ret[e];
@@ -1073,7 +1076,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     RG_STAMP(4);  // scenario epilogue computed
     if constexpr (!OBS_ONLY) {
         // gym's TimeLimit on top of the scenario (gymma block of rg_step_io): the limit ends an episode the scenario did not
-        const bool gym = q_el != nullptr;
+        constexpr bool gym = GYM;
         bool trunc = false;
         if (gym) {
             RG_LATE(el_raw);
@@ -1203,16 +1206,16 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 // round-trips through this CU's caches (workgroup-scope visibility after the barrier).  Separate
 // instantiations: the loop keeps more values live (at N = 5 the thread-per-env kernel goes from 237 to
 // 313 VGPRs) and would slow the single-step launch down.
-template <int SCN, int GW, bool OBS_ONLY, int NT, bool ROLLOUT>
+template <int SCN, int GW, bool OBS_ONLY, int NT, bool ROLLOUT, bool GYM = false>
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ Lds<GW> lds;
     const int N = NT > 0 ? NT : a.p.n_agents;
     if constexpr (!ROLLOUT) {
-        step_once<SCN, GW, OBS_ONLY, NT, true>(a, lds, step_view(a, 0, N, a.p.obs_dim));
+        step_once<SCN, GW, OBS_ONLY, NT, true, GYM>(a, lds, step_view(a, 0, N, a.p.obs_dim));
     } else {
         for (int t = 0; t < a.num_steps; ++t) {
             if (t) __syncthreads();
-            step_once<SCN, GW, OBS_ONLY, NT, false>(a, lds, step_view(a, t, N, a.p.obs_dim));
+            step_once<SCN, GW, OBS_ONLY, NT, false, false>(a, lds, step_view(a, t, N, a.p.obs_dim));
         }
     }
 }
@@ -1267,6 +1270,14 @@ static hipError_t launch_step_scn(const KernelArgs &a_in, hipStream_t stream) {
     a.envs_per_wave = epw;
 #endif
     const int grid = (a.E + epw - 1) / epw;
+    if constexpr (!OBS_ONLY && !ROLLOUT) {
+        if (a.io.elapsed) {  // gymma block: its own instantiations (generic agent count)
+            if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, false, true>), dim3(grid), dim3(WAVE), 0, stream, a);
+            else if (gw == 16) hipLaunchKernelGGL((step_kernel<SCN, 16, false, 0, false, true>), dim3(grid), dim3(WAVE), 0, stream, a);
+            else hipLaunchKernelGGL((step_kernel<SCN, 8, false, 0, false, true>), dim3(grid), dim3(WAVE), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
     if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, OBS_ONLY, 0, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
     else if (gw == 16) hipLaunchKernelGGL((step_kernel<SCN, 16, OBS_ONLY, 0, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
     else if constexpr (OBS_ONLY) hipLaunchKernelGGL((step_kernel<SCN, 8, true, 0, false>), dim3(grid), dim3(WAVE), 0, stream, a);
@@ -1291,6 +1302,13 @@ static hipError_t launch_step_group(const KernelArgs &a, hipStream_t stream) {
         case RG_SCN_SIMPLE:
             return launch_step_scn<RG_SCN_SIMPLE, OBS_ONLY, ROLLOUT>(a, stream);
         case RG_SCN_ARCTIC_TRANSPORT:
+            if constexpr (!OBS_ONLY && !ROLLOUT) {
+                if (a.io.elapsed) {
+                    hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false, 0, false, true>), dim3((a.E + 15) / 16),
+                                       dim3(WAVE), 0, stream, a);
+                    return hipGetLastError();
+                }
+            }
             hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, OBS_ONLY, 0, ROLLOUT>), dim3((a.E + 15) / 16), dim3(WAVE), 0,
                                stream, a);
             return hipGetLastError();
