@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 PMC_PROFILE = os.path.join("profiles", "r2_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
 PMC_FALLBACKS = (os.path.join("profiles", "r2a_xcd_pmc_summary.csv"), os.path.join("profiles", "r1_final_pmc_summary.csv"))
-HEADLINE_KERNEL = "rg::step_kernel<0, 8, false, 5, false>"
+HEADLINE_KERNEL = "rg::step_kernel<0, 8, false, 5, false"   # <PCP, GW 8, step, N 5, single launch[, no gymma block]>
 SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4     # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2400 MHz, one wave issues a VALU op per 4 cycles
 
 
