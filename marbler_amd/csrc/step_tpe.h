@@ -193,6 +193,99 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     return sweeps;
 }
 
+// ------------------------------------------------------------------ coalesced stores through LDS
+// One lane owns one env, so a lane's own stores are strided by the env's record: a wave-level store instruction
+// touches 64 cache lines and becomes up to 64 write requests to L2 (measured at a chip-filling batch: 52.7 M write
+// requests per launch for 231 MB, TCC busy 91 %).  The wave's 64 records are contiguous in memory, so each lane writes
+// its record to the wave's LDS block instead and the wave copies the block out with lane-contiguous 16-byte stores
+// (16 lines per instruction).  One wave per workgroup and all 64 lanes take part (lanes past the end of the batch
+// repeat its last env, see step_kernel): LDS operations of a wave execute in program order, no barrier is involved;
+// the fences only pin the compiler's order.
+constexpr int STAGE_DW = 4096;  // 16 KB: eight one-wave workgroups per CU (two waves per SIMD) fit the CU's 160 KB
+typedef float f4v __attribute__((ext_vector_type(4), may_alias));
+typedef float f2v __attribute__((ext_vector_type(2), may_alias));
+
+struct Stage {
+    float *buf;   // the wave's LDS block, STAGE_DW floats
+    int lane;     // lane = env slot of the wave
+    int nact;     // envs of this wave (64 except in the batch's last wave)
+    size_t env0;  // first env of the wave
+#ifdef RG_TPE_GUARD  // diagnostic build (tools/guard_probe.py): a store outside its array is dropped and flagged in
+    int *flag;    // done_count[0] instead of faulting
+    int E;
+#endif
+};
+#ifdef RG_TPE_GUARD
+#define RG_GUARDED(dst, lo, hi, code, stmt) \
+    if ((dst) < (lo) || (dst) >= (hi)) atomicOr(sg.flag, (code)); else { stmt; }
+#else
+#define RG_GUARDED(dst, lo, hi, code, stmt) stmt
+#endif
+
+__device__ __forceinline__ void stage_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// g[0 .. ndw) <- buf[0 .. ndw): the wave's contiguous span of one array of REC floats per env (ndw = nact * REC).
+// All LDS reads of the span are issued before the first store (one LDS round trip, not one per store).
+template <int REC>
+__device__ __forceinline__ void copy_span(const Stage &sg, const float *buf, float *g, int ndw, const float *lo = nullptr,
+                                          const float *hi = nullptr) {
+    if (((ndw | static_cast<int>(reinterpret_cast<uintptr_t>(g) >> 2)) & 3) == 0) {
+        constexpr int IT = (REC + 3) / 4;  // 64 REC floats = 16 REC units of 16 bytes, 64 units per instruction
+        f4v t[IT];
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int u = 4 * sg.lane + 4 * WAVE * q;
+            t[q] = *reinterpret_cast<const f4v *>(buf + (u < ndw ? u : 0));
+        }
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int u = 4 * sg.lane + 4 * WAVE * q;
+            if (u < ndw) {
+                RG_GUARDED(g + u, lo, hi - 3, 1 << 8, *reinterpret_cast<f4v *>(g + u) = t[q]);
+            }
+        }
+    } else {  // the batch's last wave, or a base that is not 16-byte aligned
+        for (int u = sg.lane; u < ndw; u += WAVE) {
+            RG_GUARDED(g + u, lo, hi, 2 << 8, g[u] = buf[u]);
+        }
+    }
+}
+
+// for env in [0, nact): g[env * gs + (0 .. run)) <- buf[env * run + (0 .. run)) (the LDS block holds the runs back to
+// back), in units of W dwords (run, gs multiples of W; at most 64 units per run).  One iteration moves 64 / upr whole
+// runs: a lane keeps its place (env within the iteration, unit within the run) and only the wave-uniform env base
+// advances.  Four iterations at a time: their LDS reads are issued together, then their stores.
+template <int W>
+__device__ __forceinline__ void copy_runs(const Stage &sg, const float *buf, float *g, int run, int gs, const float *lo = nullptr,
+                                          const float *hi = nullptr) {
+    typedef float unit_t __attribute__((ext_vector_type(W == 1 ? 1 : W), may_alias));
+    constexpr int UNR = 4;
+    const int upr = run / W;  // units per run (wave-uniform)
+    const float rcp = __builtin_amdgcn_rcpf(static_cast<float>(upr));
+    // small non-negative integers: floor((n + 0.5) / upr) is exact through the approximate reciprocal
+    const int epi = __builtin_amdgcn_readfirstlane(static_cast<int>(64.5f * rcp));  // envs per iteration
+    const int le = static_cast<int>((static_cast<float>(sg.lane) + 0.5f) * rcp);    // this lane's env in the iteration
+    const int r = sg.lane - le * upr;                                               // and its unit in the run
+    const unsigned dst0 = static_cast<unsigned>(le * gs + r * W);
+    const int last = le < epi ? sg.nact - le : 0;  // this lane moves the iterations whose first env is below `last`
+    for (int e0 = 0; e0 < sg.nact; e0 += UNR * epi) {
+        unit_t t[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int eq = e0 + q * epi;
+            t[q] = *reinterpret_cast<const unit_t *>(buf + (eq < last ? (eq * upr + sg.lane) * W : 0));
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int eq = e0 + q * epi;
+            if (eq < last) {
+                float *dst = g + static_cast<size_t>(eq) * gs + dst0;
+                RG_GUARDED(dst, lo, hi - (W - 1), 4 << 8, *reinterpret_cast<unit_t *>(dst) = t[q]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ neighbour rows
 // obs slots 1..K of agent A from the own-observation rows of the K nearest others (ascending
 // squared distance, ties -> lower index); K >= N-1: all others in index order.
@@ -250,10 +343,51 @@ __device__ __forceinline__ void write_obs_with_neighbours(const float (&x)[N], c
     });
 }
 
+// the same rows through the wave's LDS block (PredatorCapturePrey, Warehouse: D = OD (Knb + 1), every element of a
+// row is written): RP rows of all 64 envs at a time, RP fixed at compile time from the largest D the instantiation
+// can see (Knb <= N - 1), each batch copied out as 64 runs of RP * D floats
+template <int N, int OD>
+__device__ __forceinline__ void write_obs_staged(const float (&x)[N], const float (&y)[N], const float (&own)[N][OD],
+                                                 int Knb, const Stage &sg, float *obs, int D) {
+    constexpr int RP = (STAGE_DW / (WAVE * OD * N)) < N ? (STAGE_DW / (WAVE * OD * N)) : N;
+    static_assert(RP >= 1, "one observation row of the whole wave must fit the staging block");
+    float *g0 = obs + sg.env0 * N * D;  // the wave's first env
+    sfor<0, N>([&](auto AA) {
+        constexpr int A = decltype(AA)::value;
+        constexpr int A0 = A - A % RP, CNT = (A0 + RP <= N) ? RP : N - A0;  // this row's batch: rows A0 .. A0 + CNT
+        float *row = sg.buf + (sg.lane * CNT + (A - A0)) * D;
+        if constexpr (OD == 4) {
+            *reinterpret_cast<f4v *>(row) = f4v{own[A][0], own[A][1], own[A][2], own[A][3]};
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < OD; ++cc) row[cc] = own[A][cc];
+        }
+        write_neighbours<N, OD, A>(x, y, own, Knb, row);
+        if constexpr (A == A0 + CNT - 1) {
+            stage_fence();
+#ifdef RG_TPE_GUARD
+            const float *lo = obs, *hi = obs + static_cast<size_t>(sg.E) * N * D;
+#else
+            const float *lo = nullptr, *hi = nullptr;
+#endif
+            constexpr int W = OD % 4 == 0 ? 4 : OD % 2 == 0 ? 2 : 1;  // D = OD (Knb + 1) is a multiple of W
+            copy_runs<W>(sg, sg.buf, g0 + A0 * D, CNT * D, N * D, lo, hi);
+            stage_fence();
+        }
+    });
+}
+
 // ------------------------------------------------------------------ one env step on one lane
 // returns whether the episode ended (roboEnv.py:38-96 + the scenario's step())
 template <int SCN, int N>
-__device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv, const int e, int &rc_raw) {
+__device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv, const int e, int &rc_raw, const Stage &sg) {
+#ifdef RG_STAMPS  // diagnostic build only (tools/stamp_probe.py): wave-cycle stamps of the step's phases, written over
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();  // io.qp_sweeps of the wave's first 8 envs
+    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RG_TSTAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
+#else
+#define RG_TSTAMP(i)
+#endif
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
     const size_t eN = static_cast<size_t>(e) * N;
@@ -284,6 +418,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = q_carry[eN + i];  // dist incl. the pending sub-step (first used at the period end)
     }
+#ifdef RG_STAMPS
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]), "v"(y[i]), "v"(th[i]), "v"(act[i]), "v"(acc[i]));
+    RG_TSTAMP(0);  // inputs loaded
+#endif
     // (step counter, reset counter and statistics words are fetched in the epilogue, where they are used: this kernel
     // has no register to spare -- a value more live through the step costs its second wave per SIMD -- and the second
     // wave hides the latency)
@@ -335,6 +474,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         for (int i = 0; i < N; ++i) sincos_spec(th[i], s[i], c[i]);
         const int sw = controller<N>(p, k, x, y, c, s, gx, gy, v, w);
         max_sweeps = sw > max_sweeps ? sw : max_sweeps;
+#ifdef RG_STAMPS
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("" ::"v"(v[i]), "v"(w[i]));
+        if (it0 == 0) RG_TSTAMP(1);  // first controller
+#endif
 #ifdef RG_TPE_DIAG
         diag |= sw << (it0 == 0 ? 8 : 0);
 #endif
@@ -459,7 +603,13 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             bx[i] = x[i];
             by[i] = y[i];
         }
+#ifdef RG_STAMPS
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]), "v"(y[i]), "v"(th[i]));
+        if (it0 == 0) RG_TSTAMP(2);  // first period
+#endif
     }
+    RG_TSTAMP(3);  // all periods
     float dist[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dist[i] = viol ? acc[i] : acc[i] - last[i];
@@ -472,6 +622,15 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     float reward[N];
     const int steps = q_steps[e] + 1;
     if (a.auto_reset) rc_raw = a.st.reset_count[e];  // for the fused reset, should this env finish
+    // the statistics words ride the same memory round trip (the pair arrays of the QP are dead here: no pressure)
+    float st_ret = 0.0f, st_sum = 0.0f;
+    int st_cnt = 0, st_steps = 0;
+    if (stats) {
+        st_ret = q_ret[e];
+        st_sum = q_sum[e];
+        st_cnt = q_cnt[e];
+        st_steps = q_stp[e];
+    }
 
     if constexpr (SCN == RG_SCN_PREDATOR_CAPTURE_PREY) {
         const int P = p.num_prey;
@@ -551,7 +710,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 own[i][4] = p.sensing_radius[i];
                 own[i][5] = p.capture_radius[i];
             }
-            write_obs_with_neighbours<N, 6>(x, y, own, p.num_neighbors, obs_env, D);
+            write_obs_staged<N, 6>(x, y, own, p.num_neighbors, sg, sv.io.obs, D);
         } else {
             float own[N][4];
 #pragma unroll
@@ -561,7 +720,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 own[i][2] = qx[i];
                 own[i][3] = qy[i];
             }
-            write_obs_with_neighbours<N, 4>(x, y, own, p.num_neighbors, obs_env, D);
+            write_obs_staged<N, 4>(x, y, own, p.num_neighbors, sg, sv.io.obs, D);
         }
         float r;
         if (viol) {
@@ -589,7 +748,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             own[i][1] = y[i];
             own[i][2] = loaded[i] ? 1.0f : 0.0f;
         }
-        write_obs_with_neighbours<N, 3>(x, y, own, p.num_neighbors, obs_env, D);
+        write_obs_staged<N, 3>(x, y, own, p.num_neighbors, sg, sv.io.obs, D);
         if (viol) {
 #pragma unroll
             for (int i = 0; i < N; ++i) reward[i] = p.violation_reward;
@@ -791,27 +950,37 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     }
 
     // ---- stores
+    RG_TSTAMP(4);  // scenario epilogue (observation rows already on their way)
     bool trunc = false;
     {
-        float *X = a.st.poses + eN * 3;
         float rsum = 0.0f;
-        float st_ret = 0.0f, st_sum = 0.0f;
-        int st_cnt = 0, st_steps = 0;
-        if (stats) {
-            st_ret = q_ret[e];
-            st_sum = q_sum[e];
-            st_cnt = q_cnt[e];
-            st_steps = q_stp[e];
-        }
+        {   // poses, carried distance, rewards and distances: the wave's span of each array through the LDS block
+            float *sp = sg.buf + sg.lane * (3 * N), *sc = sg.buf + WAVE * (3 * N) + sg.lane * N;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            X[i] = x[i];
-            X[N + i] = y[i];
-            X[2 * N + i] = th[i];
-            a.st.carry_dist[eN + i] = last[i];
-            sv.io.reward[eN + i] = reward[i];
-            sv.io.dist_travelled[eN + i] = dist[i];
-            rsum = rsum + reward[i];
+            for (int i = 0; i < N; ++i) {
+                sp[i] = x[i];
+                sp[N + i] = y[i];
+                sp[2 * N + i] = th[i];
+                sc[i] = last[i];
+                sc[WAVE * N + i] = reward[i];
+                sc[2 * WAVE * N + i] = dist[i];
+                rsum = rsum + reward[i];
+            }
+            stage_fence();
+            const size_t w0 = sg.env0 * N;
+#ifdef RG_TPE_GUARD
+            const size_t EN = static_cast<size_t>(a.E) * N;
+            copy_span<3 * N>(sg, sg.buf, a.st.poses + w0 * 3, sg.nact * (3 * N), a.st.poses, a.st.poses + EN * 3);
+            copy_span<N>(sg, sg.buf + WAVE * (3 * N), a.st.carry_dist + w0, sg.nact * N, a.st.carry_dist, a.st.carry_dist + EN);
+            copy_span<N>(sg, sg.buf + WAVE * (4 * N), sv.io.reward + w0, sg.nact * N, sv.io.reward, sv.io.reward + EN);
+            copy_span<N>(sg, sg.buf + WAVE * (5 * N), sv.io.dist_travelled + w0, sg.nact * N, sv.io.dist_travelled, sv.io.dist_travelled + EN);
+#else
+            copy_span<3 * N>(sg, sg.buf, a.st.poses + w0 * 3, sg.nact * (3 * N));
+            copy_span<N>(sg, sg.buf + WAVE * (3 * N), a.st.carry_dist + w0, sg.nact * N);
+            copy_span<N>(sg, sg.buf + WAVE * (4 * N), sv.io.reward + w0, sg.nact * N);
+            copy_span<N>(sg, sg.buf + WAVE * (5 * N), sv.io.dist_travelled + w0, sg.nact * N);
+#endif
+            stage_fence();
         }
         a.st.episode_steps[e] = steps;
         // gym's TimeLimit on top of the scenario (gymma block of rg_step_io)
@@ -843,6 +1012,14 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #endif
         if (sv.io.qp_sweeps) sv.io.qp_sweeps[e] = max_sweeps;
     }
+#ifdef RG_STAMPS
+    RG_TSTAMP(5);
+    if (sg.lane == 0 && sv.io.qp_sweeps) {
+        stamps[7] = max_sweeps;
+        for (int i = 0; i < 8; ++i)
+            if (e + i < a.E) sv.io.qp_sweeps[e + i] = stamps[i];
+    }
+#endif
     return done | trunc;
 }
 
@@ -851,19 +1028,32 @@ template <int SCN, int N, bool ROLLOUT>
 // (forcing the register budget of 3 waves per SIMD with amdgpu_waves_per_eu spills ~100 VGPRs at N = 5
 // and measured 1.7x slower; the natural allocation runs 2 waves per SIMD at N = 5, 6 and 3 at N <= 4)
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
-    __shared__ Lds<WAVE> lds;
+    __shared__ union alignas(16) {
+        Lds<WAVE> reset;        // fused reset (after the step, behind a barrier)
+        float stage[STAGE_DW];  // the step's stores
+    } shm;
+    Lds<WAVE> &lds = shm.reset;
     const int chunk = xcd_chunk();
-    const int e = chunk * WAVE + threadIdx.x;
+    // All 64 lanes run the step (the staged stores are copied out by the whole wave): lanes past the end of the batch
+    // repeat its last env -- the same loads, the same values, the same stores -- and take no part in the fused reset.
+    const int e_raw = chunk * WAVE + threadIdx.x;
+    const int e = e_raw < a.E ? e_raw : a.E - 1;
+    const int left = a.E - chunk * WAVE;
+#ifdef RG_TPE_GUARD
+    const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE,
+                   a.st.done_count, a.E};
+#else
+    const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE};
+#endif
     const int num_steps = ROLLOUT ? a.num_steps : 1;  // rg_rollout: no device-wide synchronisation between steps
     for (int t = 0; t < num_steps; ++t) {
         if (t) __syncthreads();  // the previous step's stores and resets are visible to the wave
-        bool done = false;
         int rc_raw = -1;
-        if (e < a.E) done = step_env<SCN, N>(a, step_view(a, t, N, a.p.obs_dim), e, rc_raw);
+        const bool done = step_env<SCN, N>(a, step_view(a, t, N, a.p.obs_dim), e, rc_raw, sg);
         // fused auto-reset (scenario.reset(); ~1 env in 70 per step): the whole wave resets each finished
         // env together, as one 64-lane group of the shared sampler
         if (a.auto_reset) {
-            unsigned long long todo = __ballot(done);
+            unsigned long long todo = __ballot(done & (e_raw < a.E));
             if (todo) __syncthreads();  // the wave's state stores are complete before other lanes rewrite them
             while (todo) {
                 const int i = __builtin_ctzll(todo);

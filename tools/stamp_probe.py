@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 import torch
 from marbler_amd import VecRobotariumEnv
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+TPE = os.environ.get("RG_STEP_KERNEL") == "tpe"   # thread-per-env kernel: 64 envs per wave (E a multiple of 64)
 env = VecRobotariumEnv("PredatorCapturePrey", E, overrides={"predator": 3, "capture": 2, "n_agents": 5}, collect_qp_stats=True)
 acts = torch.randint(0, 5, (64, E, 5), device=env.device, dtype=torch.int32)
 env.reset()
@@ -20,7 +21,7 @@ n = 0
 for i in range(300):
     env.step(acts[i % 64])
     if i >= 100:
-        s = env.qp_sweeps.view(-1, 8).double().cpu()
+        s = (env.qp_sweeps.view(-1, 64)[:, :8] if TPE else env.qp_sweeps.view(-1, 8)).double().cpu()
         acc += s.mean(0)
         mx = torch.maximum(mx, s.max(0).values)
         n += 1
