@@ -421,7 +421,9 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #ifdef RG_STAMPS
 #pragma unroll
     for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]), "v"(y[i]), "v"(th[i]), "v"(act[i]), "v"(acc[i]));
+#ifndef RG_STAMPS_EPI
     RG_TSTAMP(0);  // inputs loaded
+#endif
 #endif
     // (step counter, reset counter and statistics words are fetched in the epilogue, where they are used: this kernel
     // has no register to spare -- a value more live through the step costs its second wave per SIMD -- and the second
@@ -477,7 +479,9 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #ifdef RG_STAMPS
 #pragma unroll
         for (int i = 0; i < N; ++i) asm volatile("" ::"v"(v[i]), "v"(w[i]));
+#ifndef RG_STAMPS_EPI
         if (it0 == 0) RG_TSTAMP(1);  // first controller
+#endif
 #endif
 #ifdef RG_TPE_DIAG
         diag |= sw << (it0 == 0 ? 8 : 0);
@@ -606,7 +610,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #ifdef RG_STAMPS
 #pragma unroll
         for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]), "v"(y[i]), "v"(th[i]));
+#ifndef RG_STAMPS_EPI
         if (it0 == 0) RG_TSTAMP(2);  // first period
+#else
+        if (it0 != 0) RG_TSTAMP(2);  // last period (the epilogue's loads are issued after it)
+#endif
 #endif
     }
     RG_TSTAMP(3);  // all periods
@@ -699,6 +707,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         } else {
             for (int q = 0; q < P; ++q) prey_step(pl[2 * q], pl[2 * q + 1], sen[q] != 0, cap[q] != 0, q);
         }
+#ifdef RG_STAMPS_EPI  // (with RG_STAMPS) slots 0..2 mark points inside the PredatorCapturePrey epilogue instead
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("" ::"v"(qx[i]), "v"(qy[i]));
+        RG_TSTAMP(0);  // prey tracked
+#endif
         if (p.capability_aware) {
             float own[N][6];
 #pragma unroll
@@ -721,6 +734,9 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 own[i][3] = qy[i];
             }
             write_obs_staged<N, 4>(x, y, own, p.num_neighbors, sg, sv.io.obs, D);
+#ifdef RG_STAMPS_EPI
+            RG_TSTAMP(1);  // observation rows written and copied out
+#endif
         }
         float r;
         if (viol) {
