@@ -210,6 +210,7 @@ struct Stage {
     int lane;     // lane = env slot of the wave
     int nact;     // envs of this wave (64 except in the batch's last wave)
     size_t env0;  // first env of the wave
+    size_t e;     // this lane's env (lanes past the end of the batch: its last env)
 #ifdef RG_TPE_GUARD  // diagnostic build (tools/guard_probe.py): a store outside its array is dropped and flagged in
     int *flag;    // done_count[0] instead of faulting
     int E;
@@ -327,42 +328,26 @@ __device__ __forceinline__ void write_neighbours(const float (&x)[N], const floa
     }
 }
 
-template <int N, int OD>
-__device__ __forceinline__ void write_obs_with_neighbours(const float (&x)[N], const float (&y)[N],
-                                                          const float (&own)[N][OD], int Knb, float *obs_env, int D) {
-    sfor<0, N>([&](auto AA) {
-        constexpr int A = decltype(AA)::value;
-        float *row = obs_env + A * D;
-        if constexpr (OD == 4) {
-            *reinterpret_cast<float4 *>(row) = make_float4(own[A][0], own[A][1], own[A][2], own[A][3]);
-        } else {
-#pragma unroll
-            for (int cc = 0; cc < OD; ++cc) row[cc] = own[A][cc];
-        }
-        write_neighbours<N, OD, A>(x, y, own, Knb, row);
-    });
-}
-
-// the same rows through the wave's LDS block (PredatorCapturePrey, Warehouse: D = OD (Knb + 1), every element of a
-// row is written): RP rows of all 64 envs at a time, RP fixed at compile time from the largest D the instantiation
-// can see (Knb <= N - 1), each batch copied out as 64 runs of RP * D floats
-template <int N, int OD>
-__device__ __forceinline__ void write_obs_staged(const float (&x)[N], const float (&y)[N], const float (&own)[N][OD],
-                                                 int Knb, const Stage &sg, float *obs, int D) {
-    constexpr int RP = (STAGE_DW / (WAVE * OD * N)) < N ? (STAGE_DW / (WAVE * OD * N)) : N;
+// The observation rows of the wave's envs: row A of this lane's env is written by fn(integral_constant A, row
+// pointer) -- every element of the D floats.  When rows are whole 16-byte units (D a multiple of 4: the benchmark
+// formats) they go through the wave's LDS block in batches of RP rows of all 64 envs, RP fixed at compile time from
+// DMAX, the largest D the instantiation can see, each batch copied out as 64 runs of rows x D floats.  Otherwise the
+// copy would move 4 bytes per lane and cost more LDS round trips than the stores it saves: the lane writes its rows
+// to memory itself.
+template <int N, int DMAX, typename F>
+__device__ __forceinline__ void stage_obs_rows(const Stage &sg, float *obs, int D, F &&fn) {
+    constexpr int RP = (STAGE_DW / (WAVE * DMAX)) < N ? (STAGE_DW / (WAVE * DMAX)) : N;
     static_assert(RP >= 1, "one observation row of the whole wave must fit the staging block");
+    if ((D & 3) != 0) {
+        float *mine = obs + sg.e * N * D;
+        sfor<0, N>([&](auto AA) { fn(AA, mine + decltype(AA)::value * D); });
+        return;
+    }
     float *g0 = obs + sg.env0 * N * D;  // the wave's first env
     sfor<0, N>([&](auto AA) {
         constexpr int A = decltype(AA)::value;
         constexpr int A0 = A - A % RP, CNT = (A0 + RP <= N) ? RP : N - A0;  // this row's batch: rows A0 .. A0 + CNT
-        float *row = sg.buf + (sg.lane * CNT + (A - A0)) * D;
-        if constexpr (OD == 4) {
-            *reinterpret_cast<f4v *>(row) = f4v{own[A][0], own[A][1], own[A][2], own[A][3]};
-        } else {
-#pragma unroll
-            for (int cc = 0; cc < OD; ++cc) row[cc] = own[A][cc];
-        }
-        write_neighbours<N, OD, A>(x, y, own, Knb, row);
+        fn(AA, sg.buf + (sg.lane * CNT + (A - A0)) * D);
         if constexpr (A == A0 + CNT - 1) {
             stage_fence();
 #ifdef RG_TPE_GUARD
@@ -370,10 +355,27 @@ __device__ __forceinline__ void write_obs_staged(const float (&x)[N], const floa
 #else
             const float *lo = nullptr, *hi = nullptr;
 #endif
-            constexpr int W = OD % 4 == 0 ? 4 : OD % 2 == 0 ? 2 : 1;  // D = OD (Knb + 1) is a multiple of W
-            copy_runs<W>(sg, sg.buf, g0 + A0 * D, CNT * D, N * D, lo, hi);
+            copy_runs<4>(sg, sg.buf, g0 + A0 * D, CNT * D, N * D, lo, hi);
             stage_fence();
         }
+    });
+}
+
+// own row + the rows of the Knb nearest others (PredatorCapturePrey, Warehouse, Simple: D >= OD (Knb + 1); `tail`
+// writes whatever follows the neighbour slots)
+template <int N, int OD, int DMAX, typename T>
+__device__ __forceinline__ void write_obs_staged(const float (&x)[N], const float (&y)[N], const float (&own)[N][OD],
+                                                 int Knb, const Stage &sg, float *obs, int D, T &&tail) {
+    stage_obs_rows<N, DMAX>(sg, obs, D, [&](auto AA, float *row) {
+        constexpr int A = decltype(AA)::value;
+        if constexpr (OD == 4) {
+            *reinterpret_cast<f4v *>(row) = f4v{own[A][0], own[A][1], own[A][2], own[A][3]};
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < OD; ++cc) row[cc] = own[A][cc];
+        }
+        write_neighbours<N, OD, A>(x, y, own, Knb, row);
+        tail(row);
     });
 }
 
@@ -624,7 +626,6 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 
     // ---- scenario epilogue
     const int D = p.obs_dim;
-    float *obs_env = sv.io.obs + eN * D;
     bool done = false;
     int remaining = -1;
     float reward[N];
@@ -723,7 +724,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 own[i][4] = p.sensing_radius[i];
                 own[i][5] = p.capture_radius[i];
             }
-            write_obs_staged<N, 6>(x, y, own, p.num_neighbors, sg, sv.io.obs, D);
+            write_obs_staged<N, 6, 6 * N>(x, y, own, p.num_neighbors, sg, sv.io.obs, D, [](float *) {});
         } else {
             float own[N][4];
 #pragma unroll
@@ -733,7 +734,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 own[i][2] = qx[i];
                 own[i][3] = qy[i];
             }
-            write_obs_staged<N, 4>(x, y, own, p.num_neighbors, sg, sv.io.obs, D);
+            write_obs_staged<N, 4, 4 * N>(x, y, own, p.num_neighbors, sg, sv.io.obs, D, [](float *) {});
 #ifdef RG_STAMPS_EPI
             RG_TSTAMP(1);  // observation rows written and copied out
 #endif
@@ -764,7 +765,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             own[i][1] = y[i];
             own[i][2] = loaded[i] ? 1.0f : 0.0f;
         }
-        write_obs_staged<N, 3>(x, y, own, p.num_neighbors, sg, sv.io.obs, D);
+        write_obs_staged<N, 3, 3 * N>(x, y, own, p.num_neighbors, sg, sv.io.obs, D, [](float *) {});
         if (viol) {
 #pragma unroll
             for (int i = 0; i < N; ++i) reward[i] = p.violation_reward;
@@ -798,11 +799,12 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             own[i][0] = x[i];
             own[i][1] = y[i];
         }
-        write_obs_with_neighbours<N, 2>(x, y, own, N - 1, obs_env, D);
+        write_obs_staged<N, 2, 2 * N + 2>(x, y, own, N - 1, sg, sv.io.obs, D, [&](float *row) {  // simple.py:98: D = 2 (N + 1)
+            row[2 * N] = goal_x;
+            row[2 * N + 1] = goal_y;
+        });
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            obs_env[i * D + 2 * N] = goal_x;
-            obs_env[i * D + 2 * N + 1] = goal_y;
             if (viol) {
                 reward[i] = p.violation_reward;
             } else {
@@ -841,10 +843,9 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             surround[i][6] = static_cast<float>(grid[row[i] * 12 + right]);
             surround[i][7] = static_cast<float>(grid[down * 12 + right]);
         }
-        sfor<0, N>([&](auto AA) {
+        stage_obs_rows<N, 30>(sg, sv.io.obs, D, [&](auto AA, float *o) {  // ArcticTransport.py:19: D = 30
             constexpr int A = decltype(AA)::value;
             constexpr int o0 = A == 0 ? 1 : A == 1 ? 0 : A == 2 ? 3 : 2, o1 = A < 2 ? 2 : 0, o2 = A < 2 ? 3 : 1;
-            float *o = obs_env + A * D;
             o[0] = x[A];
             o[1] = y[A];
             o[2] = static_cast<float>(here[A]);
@@ -891,9 +892,9 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         for (int i = 0; i < 4; ++i) msg[i] = i < N ? act[i < N ? i : 0] % 4 : a.st.messages[4 * e + i];
         int zone0 = a.st.zone_load[2 * e], zone1 = a.st.zone_load[2 * e + 1];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            load[i] = a.st.load[eN + i];
-            float *o = obs_env + i * D;
+        for (int i = 0; i < N; ++i) load[i] = a.st.load[eN + i];
+        stage_obs_rows<N, 11>(sg, sv.io.obs, D, [&](auto II, float *o) {  // D = 9, or 11 with the capabilities
+            constexpr int i = decltype(II)::value;
             o[0] = x[i];
             o[1] = y[i];
             o[2] = static_cast<float>(load[i]);
@@ -905,7 +906,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 o[9] = static_cast<float>(p.torque[i]);
                 o[10] = p.agent_step[i];
             }
-        }
+        });
         float r;
         if (viol) {
             r = p.violation_reward;
@@ -1057,9 +1058,10 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     const int left = a.E - chunk * WAVE;
 #ifdef RG_TPE_GUARD
     const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE,
-                   a.st.done_count, a.E};
+                   static_cast<size_t>(e), a.st.done_count, a.E};
 #else
-    const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE};
+    const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE,
+                   static_cast<size_t>(e)};
 #endif
     const int num_steps = ROLLOUT ? a.num_steps : 1;  // rg_rollout: no device-wide synchronisation between steps
     for (int t = 0; t < num_steps; ++t) {
