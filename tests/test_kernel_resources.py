@@ -12,14 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "marbler_amd", "csrc")
 
 
-def _report(src):
+def _report(src, defines=()):
     from marbler_amd import build as hip_build
     try:
         hipcc = hip_build.hipcc_path()
     except RuntimeError:
         pytest.skip("no hipcc")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC,
-                        "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(ROOT, "tests", "kernels", src),
+                        "-Rpass-analysis=kernel-resource-usage", *[f"-D{d}" for d in defines],
+                        "-c", os.path.join(ROOT, "tests", "kernels", src),
                         "-o", os.devnull], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     out, name = {}, None
@@ -40,6 +41,7 @@ def test_thread_per_env_kernel_keeps_two_waves_per_simd():
     assert len(rep) == 3
     for name, r in rep.items():
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+        assert r["LDS Size"] <= 20 * 1024, (name, r)   # eight one-wave workgroups per CU: the staging block must leave room
         # N = 4, 5: two waves per SIMD (<= 256 VGPRs + AGPRs); N = 6 (15 pairs) has needed one wave's budget since round 1
         assert r["Occupancy"] >= (1 if "Li0ELi6ELb0E" in name else 2), (name, r)
 
@@ -52,3 +54,11 @@ def test_lane_group_kernel_fits_three_waves_per_simd_without_scratch():
         # instruction is emitted for them; a spilled VGPR is what must not happen)
         assert r["VGPRs Spill"] == 0 and r["ScratchSize"] <= 128, (name, r)
         assert r["Occupancy"] >= 3, (name, r)
+
+
+def test_diagnostic_builds_of_the_thread_per_env_kernel_still_compile():
+    """-DRG_STAMPS -DRG_STAMPS_EPI (phase stamps, tools/stamp_probe.py / epi_probe.py), -DRG_TPE_GUARD (bounds-checked
+    staged stores, tools/guard_probe.py) and -DRG_TPE_DIAG (sweep / replay masks, tools/tpe_diag.py) are never shipped
+    and only built by hand: one compile with all of them keeps the macros from rotting."""
+    rep = _report("tpe_pcp5.hip", defines=("RG_STAMPS", "RG_STAMPS_EPI", "RG_TPE_GUARD", "RG_TPE_DIAG"))
+    assert len(rep) == 3
