@@ -201,12 +201,15 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
 // (16 lines per instruction).  One wave per workgroup and all 64 lanes take part (lanes past the end of the batch
 // repeat its last env, see step_kernel): LDS operations of a wave execute in program order, no barrier is involved;
 // the fences only pin the compiler's order.
-constexpr int STAGE_DW = 4096;  // 16 KB: eight one-wave workgroups per CU (two waves per SIMD) fit the CU's 160 KB
+// 16 KB: eight one-wave workgroups per CU (two waves per SIMD) fit the CU's 160 KB; 12 KB for the instantiations that
+// run three waves per SIMD (N <= 4: twelve workgroups per CU)
+template <int N>
+constexpr int stage_dw() { return N <= 4 ? 3072 : 4096; }
 typedef float f4v __attribute__((ext_vector_type(4), may_alias));
 typedef float f2v __attribute__((ext_vector_type(2), may_alias));
 
 struct Stage {
-    float *buf;   // the wave's LDS block, STAGE_DW floats
+    float *buf;   // the wave's LDS block, stage_dw<N>() floats
     int lane;     // lane = env slot of the wave
     int nact;     // envs of this wave (64 except in the batch's last wave)
     size_t env0;  // first env of the wave
@@ -336,7 +339,7 @@ __device__ __forceinline__ void write_neighbours(const float (&x)[N], const floa
 // to memory itself.
 template <int N, int DMAX, typename F>
 __device__ __forceinline__ void stage_obs_rows(const Stage &sg, float *obs, int D, F &&fn) {
-    constexpr int RP = (STAGE_DW / (WAVE * DMAX)) < N ? (STAGE_DW / (WAVE * DMAX)) : N;
+    constexpr int RP = (stage_dw<N>() / (WAVE * DMAX)) < N ? (stage_dw<N>() / (WAVE * DMAX)) : N;
     static_assert(RP >= 1, "one observation row of the whole wave must fit the staging block");
     if ((D & 3) != 0) {
         float *mine = obs + sg.e * N * D;
@@ -972,6 +975,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     {
         float rsum = 0.0f;
         {   // poses, carried distance, rewards and distances: the wave's span of each array through the LDS block
+            static_assert(WAVE * 6 * N <= stage_dw<N>(), "the small records of the wave must fit the staging block");
             float *sp = sg.buf + sg.lane * (3 * N), *sc = sg.buf + WAVE * (3 * N) + sg.lane * N;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -1044,10 +1048,14 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 template <int SCN, int N, bool ROLLOUT>
 // (forcing the register budget of 3 waves per SIMD with amdgpu_waves_per_eu spills ~100 VGPRs at N = 5
 // and measured 1.7x slower; the natural allocation runs 2 waves per SIMD at N = 5, 6 and 3 at N <= 4)
+#ifndef RG_TPE_NO_W3
+// N <= 4 sits 3-12 VGPRs above the budget of three waves per SIMD (168): ask for it (a handful of values go to scratch)
+__attribute__((amdgpu_waves_per_eu(N <= 4 ? 3 : 1)))
+#endif
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ union alignas(16) {
         Lds<WAVE> reset;        // fused reset (after the step, behind a barrier)
-        float stage[STAGE_DW];  // the step's stores
+        float stage[stage_dw<N>()];  // the step's stores
     } shm;
     Lds<WAVE> &lds = shm.reset;
     const int chunk = xcd_chunk();

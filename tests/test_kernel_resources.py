@@ -40,9 +40,14 @@ def test_thread_per_env_kernel_keeps_two_waves_per_simd():
     rep = _report("tpe_pcp5.hip")
     assert len(rep) == 3
     for name, r in rep.items():
+        if "Li0ELi4ELb0E" in name:
+            # N = 4 sits a few registers above three waves per SIMD and is compiled for three (measured +8 % at
+            # 524288 envs): a handful of values in scratch, twelve one-wave workgroups per CU in LDS
+            assert r["Occupancy"] >= 3 and r["ScratchSize"] <= 64 and r["LDS Size"] <= 13 * 1024, (name, r)
+            continue
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
         assert r["LDS Size"] <= 20 * 1024, (name, r)   # eight one-wave workgroups per CU: the staging block must leave room
-        # N = 4, 5: two waves per SIMD (<= 256 VGPRs + AGPRs); N = 6 (15 pairs) has needed one wave's budget since round 1
+        # N = 5: two waves per SIMD (<= 256 VGPRs + AGPRs); N = 6 (15 pairs) has needed one wave's budget since round 1
         assert r["Occupancy"] >= (1 if "Li0ELi6ELb0E" in name else 2), (name, r)
 
 
