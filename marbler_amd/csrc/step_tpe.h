@@ -1049,8 +1049,11 @@ template <int SCN, int N, bool ROLLOUT>
 // (forcing the register budget of 3 waves per SIMD with amdgpu_waves_per_eu spills ~100 VGPRs at N = 5
 // and measured 1.7x slower; the natural allocation runs 2 waves per SIMD at N = 5, 6 and 3 at N <= 4)
 #ifndef RG_TPE_NO_W3
-// N <= 4 sits 3-12 VGPRs above the budget of three waves per SIMD (168): ask for it (a handful of values go to scratch)
-__attribute__((amdgpu_waves_per_eu(N <= 4 ? 3 : 1)))
+// Occupancy bought with a few scratch slots where the natural allocation misses a wave by a small margin (measured at
+// 524 288 envs, tools/n4_probe.py): N <= 4 needs 170-180 VGPRs, 168 give three waves per SIMD (5-8 values spilled:
+// +4..14 %); N = 6 needs 256 + 40, 256 give two (28-48 spilled: +21..34 %).  N = 5 fits two as it is, and three would
+// spill ~100 (1.7x slower); N >= 7 would spill 130+ and stays on the lane-group kernel.
+__attribute__((amdgpu_waves_per_eu(N <= 4 ? 3 : N == 6 ? 2 : 1)))
 #endif
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ union alignas(16) {

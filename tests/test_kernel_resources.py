@@ -45,10 +45,14 @@ def test_thread_per_env_kernel_keeps_two_waves_per_simd():
             # 524288 envs): a handful of values in scratch, twelve one-wave workgroups per CU in LDS
             assert r["Occupancy"] >= 3 and r["ScratchSize"] <= 64 and r["LDS Size"] <= 13 * 1024, (name, r)
             continue
-        assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
         assert r["LDS Size"] <= 20 * 1024, (name, r)   # eight one-wave workgroups per CU: the staging block must leave room
-        # N = 5: two waves per SIMD (<= 256 VGPRs + AGPRs); N = 6 (15 pairs) has needed one wave's budget since round 1
-        assert r["Occupancy"] >= (1 if "Li0ELi6ELb0E" in name else 2), (name, r)
+        assert r["Occupancy"] >= 2, (name, r)
+        if "Li0ELi6ELb0E" in name:
+            # N = 6 (15 pairs) needs 256 + 40 registers and is compiled for two waves per SIMD all the same: ~40 values in
+            # scratch, measured +21..34 % at 524288 envs
+            assert r["ScratchSize"] <= 256, (name, r)
+        else:   # N = 5, the benchmark instantiation: two waves per SIMD without a spill
+            assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
 
 
 def test_lane_group_kernel_fits_three_waves_per_simd_without_scratch():

@@ -9,6 +9,10 @@ from marbler_amd import VecRobotariumEnv
 CASES = [("PredatorCapturePrey", {"predator": 2, "capture": 2, "n_agents": 4}, 5),
          ("MaterialTransport", {}, 20), ("Simple", {}, 5), ("ArcticTransport", {}, 5),
          ("PredatorCapturePrey", {"predator": 2, "capture": 1, "n_agents": 3}, 5)]
+if "--n6" in sys.argv:
+    CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 3, "n_agents": 6}, 5),
+             ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}, 20),
+             ("Warehouse", {"n_agents": 6}, 5)]
 for scn, ov, nact in CASES:
     for E in (131072, 524288):
         env = VecRobotariumEnv(scn, E, overrides=ov, seed=0)
