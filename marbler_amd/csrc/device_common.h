@@ -133,16 +133,25 @@ __device__ __forceinline__ bool group_any(bool pred, int gbase) {
 }
 
 // ------------------------------------------------------------------ LDS scratch (one wavefront)
+// The step's scratch and the reset sampler's are never live together (the fused reset runs after the step's last LDS
+// read, an explicit reset runs alone), so they share the block: 7.5 KB instead of 13.5 KB per one-wave workgroup --
+// at 13.5 KB a CU's 160 KB held 11 workgroups, 2.75 waves per SIMD, whatever the register count allowed.
 template <int GW>
 struct alignas(16) Lds {
-    float prey[WAVE / GW][RG_MAX_PREY * 2];  // the env's prey block (PredatorCapturePrey)
-    float own[WAVE][8];                      // each agent's own-observation row (<= 6 floats)
-    float ax[WAVE], ay[WAVE];                // MaterialTransport sequential replay / reward sum
-    int aload[WAVE];
-    uint8_t grid[WAVE / GW][RG_ARCTIC_ROWS * RG_ARCTIC_COLS];  // ArcticTransport terrain of the env
-    uint32_t draws[WAVE / GW][MAX_DRAWS];    // reset: Philox output
-    uint8_t perm[WAVE / GW][2][64];          // reset: Fisher-Yates permutations of the grid cells (agents, prey)
-    uint8_t sel[WAVE / GW][2][64];           // reset: chosen cells
+    union {
+        struct {  // step
+            float prey[WAVE / GW][RG_MAX_PREY * 2];  // the env's prey block (PredatorCapturePrey)
+            float own[WAVE][8];                      // each agent's own-observation row (<= 6 floats)
+            float ax[WAVE], ay[WAVE];                // MaterialTransport sequential replay / reward sum
+            int aload[WAVE];
+            uint8_t grid[WAVE / GW][RG_ARCTIC_ROWS * RG_ARCTIC_COLS];  // ArcticTransport terrain of the env
+        };
+        struct {  // reset
+            uint32_t draws[WAVE / GW][MAX_DRAWS];    // Philox output
+            uint8_t perm[WAVE / GW][2][64];          // Fisher-Yates permutations of the grid cells (agents, prey)
+            uint8_t sel[WAVE / GW][2][64];           // chosen cells
+        };
+    };
 };
 
 // ------------------------------------------------------------------ reset sampler (a17)
