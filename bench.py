@@ -505,7 +505,7 @@ def main():
                          "traffic_kind": "from_committed_profile (rocprofv3 --pmc passes of this command; not measured in this run)",
                          "traffic_source": counters_src, "valu": valu,
                          "kernel": (f"rg::step_kernel<{args.scenario},GW={4 if N <= 4 else 8 if N <= 8 else 16},N={N}> (lane group per env)"
-                                    if (args.scenario != "PredatorCapturePrey" or E < 40960)
+                                    if (args.scenario != "PredatorCapturePrey" or E < 53248)
                                     else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)"),
                          "kernel_ms_avg": gpu_ms_total / K,   # HIP events around the timed region / K (back-to-back launches)
                          "kernel_ms_avg_event_pair_per_launch": kernel_ms,

@@ -29,16 +29,14 @@ struct rg_handle {
 
 // Which step kernel: both give identical results.  The lane-group kernel has the shorter chain for
 // small batches; the thread-per-env kernel takes over once the batch fills the chip.  Measured
-// cross-overs on MI355X (tools/crossover_probe.py): N = 5 at ~40k envs,
-// N = 4 and N = 6 at ~64k (N = 6 since it runs two waves per SIMD: in every scenario);
+// cross-overs on MI355X (tools/crossover_probe.py): N = 5 at ~52k envs,
+// the others at ~64k (N = 6 since it runs two waves per SIMD: in every scenario);
 // for N >= 7 the per-lane register footprint (28 pairs) leaves one wave per SIMD and the lane-group
 // kernel stays ahead.  RG_STEP_KERNEL=group|tpe forces one (tests, profiling).
 static int32_t tpe_min_envs(const rg_scenario_params &p) {
     switch (p.n_agents) {
-        case 2: case 3: return 49152;
-        case 4: return 65536;
-        case 5: return 40960;
-        case 6: return 65536;
+        case 2: case 3: case 4: case 6: return 65536;
+        case 5: return 53248;
         default: return INT32_MAX;
     }
 }
