@@ -341,7 +341,9 @@ template <int N, int DMAX, typename F>
 __device__ __forceinline__ void stage_obs_rows(const Stage &sg, float *obs, int D, F &&fn) {
     constexpr int RP = (stage_dw<N>() / (WAVE * DMAX)) < N ? (stage_dw<N>() / (WAVE * DMAX)) : N;
     static_assert(RP >= 1, "one observation row of the whole wave must fit the staging block");
-    if ((D & 3) != 0) {
+    // D > DMAX: a parameter block that asks for more neighbour slots than there are other agents (rows wider than the
+    // agents fill, misc.py:20-25 / PredatorCapturePrey.py:198-201) -- the batch would overrun the staging block
+    if ((D & 3) != 0 || D > DMAX) {
         float *mine = obs + sg.e * N * D;
         sfor<0, N>([&](auto AA) { fn(AA, mine + decltype(AA)::value * D); });
         return;

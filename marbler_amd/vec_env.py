@@ -59,27 +59,28 @@ class VecRobotariumEnv(object):
         E, N, D, P = self.E, self.N, self.D, max(self.P, 1)
         dev = self.device
         f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        zeros = self._alloc      # every device array of this object comes from here (tests carve them out of a guarded slab)
         # ---- state (rg_state)
-        self.poses = torch.zeros(E, 3, N, dtype=f32, device=dev)
-        self.carry_dist = torch.zeros(E, N, dtype=f32, device=dev)
-        self.episode_steps = torch.zeros(E, dtype=i32, device=dev)
-        self.reset_count = torch.zeros(E, dtype=i32, device=dev)
-        self.prey_loc = torch.zeros(E, P, 2, dtype=f32, device=dev)
-        self.prey_sensed = torch.zeros(E, P, dtype=u8, device=dev)
-        self.prey_captured = torch.zeros(E, P, dtype=u8, device=dev)
-        self.loaded = torch.zeros(E, N, dtype=u8, device=dev)
-        self.load = torch.zeros(E, N, dtype=i32, device=dev)
-        self.zone_load = torch.zeros(E, 2, dtype=i32, device=dev)
-        self.messages = torch.zeros(E, 4, dtype=i32, device=dev)
-        self.grid = torch.zeros(E, 96, dtype=u8, device=dev)
-        self.goal_col = torch.ones(E, dtype=i32, device=dev)
-        self.pixel_type = torch.zeros(E, N, dtype=u8, device=dev)
-        self.reached_goal = torch.zeros(E, N, dtype=u8, device=dev)
+        self.poses = zeros((E, 3, N,), f32)
+        self.carry_dist = zeros((E, N,), f32)
+        self.episode_steps = zeros((E,), i32)
+        self.reset_count = zeros((E,), i32)
+        self.prey_loc = zeros((E, P, 2,), f32)
+        self.prey_sensed = zeros((E, P,), u8)
+        self.prey_captured = zeros((E, P,), u8)
+        self.loaded = zeros((E, N,), u8)
+        self.load = zeros((E, N,), i32)
+        self.zone_load = zeros((E, 2,), i32)
+        self.messages = zeros((E, 4,), i32)
+        self.grid = zeros((E, 96,), u8)
+        self.goal_col = zeros((E,), i32, fill=1)
+        self.pixel_type = zeros((E, N,), u8)
+        self.reached_goal = zeros((E, N,), u8)
         # ---- rollout statistics (misc.py:151-206 accumulators, on device)
-        self.ep_return = torch.zeros(E, dtype=f32, device=dev)
-        self.done_return_sum = torch.zeros(E, dtype=f32, device=dev)
-        self.done_count = torch.zeros(E, dtype=i32, device=dev)
-        self.done_steps_sum = torch.zeros(E, dtype=i32, device=dev)
+        self.ep_return = zeros((E,), f32)
+        self.done_return_sum = zeros((E,), f32)
+        self.done_count = zeros((E,), i32)
+        self.done_steps_sum = zeros((E,), i32)
         # ---- scratch of the lane-group kernel: every env's NEXT initial state, drawn ahead of time (derived data, not
         # part of a snapshot).  Large batches run the thread-per-env kernel, which has no use for it.
         self.next_init = self.next_episode = None
@@ -87,31 +88,10 @@ class VecRobotariumEnv(object):
             stride = self.lib.rg_next_init_stride(C.byref(params))
             if stride <= 0:
                 raise _lib.RobogymError("rg_next_init_stride failed: " + self.lib.rg_last_error().decode())
-            self.next_init = torch.zeros(E, stride, dtype=f32, device=dev)
-            self.next_episode = torch.full((E,), -1, dtype=i32, device=dev)
-        # ---- step outputs (rg_step_io): views of ONE allocation, so a host-side consumer (the single-env
-        # Wrapper) fetches everything a step returns with one device-to-host copy
-        sizes = [("obs", E * N * D * 4), ("reward", E * N * 4), ("dist_travelled", E * N * 4), ("remaining", E * 4),
-                 ("done_u8", E), ("violation", E)]
-        offs, total = {}, 0
-        for name, nbytes in sizes:
-            offs[name] = total
-            total += (nbytes + 15) // 16 * 16
-        self._out_arena = torch.zeros(total, dtype=u8, device=dev)
-        self._out_offsets = offs
-
-        def view(name, nbytes, dtype, shape):
-            return self._out_arena[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
-
-        self.obs = view("obs", E * N * D * 4, f32, (E, N, D))
-        self.reward = view("reward", E * N * 4, f32, (E, N))
-        self.dist_travelled = view("dist_travelled", E * N * 4, f32, (E, N))
-        self.remaining = view("remaining", E * 4, i32, (E,))
-        self.remaining.fill_(-1)
-        self.done_u8 = view("done_u8", E, u8, (E,))
-        self.done = self.done_u8.view(torch.bool)   # the same bytes (the kernel writes 0 / 1): no conversion launch per step
-        self.violation = view("violation", E, u8, (E,))
-        self.qp_sweeps = torch.zeros(E, dtype=i32, device=dev) if collect_qp_stats else None
+            self.next_init = zeros((E, stride,), f32)
+            self.next_episode = zeros((E,), i32, fill=-1)
+        self._alloc_outputs()
+        self.qp_sweeps = zeros((E,), i32) if collect_qp_stats else None
 
         if dev.index is None:
             self.device = dev = torch.device("cuda", torch.cuda.current_device())
@@ -134,9 +114,41 @@ class VecRobotariumEnv(object):
                                  self.remaining.data_ptr(),
                                  self.qp_sweeps.data_ptr() if self.qp_sweeps is not None else None)
         self._io_ref = C.byref(self._io)
-        self._actions_i32 = torch.zeros(E, N, dtype=i32, device=dev)
+        self._actions_i32 = zeros((E, N), i32)
         self.time_limit = 0
         self.elapsed = self.truncated = self.ended = self.reward_sum = None
+
+    def _alloc_outputs(self):
+        """Step outputs (rg_step_io): views of ONE allocation, so a host-side consumer (the single-env Wrapper)
+        fetches everything a step returns with one device-to-host copy."""
+        E, N, D = self.E, self.N, self.D
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        sizes = [("obs", E * N * D * 4), ("reward", E * N * 4), ("dist_travelled", E * N * 4), ("remaining", E * 4),
+                 ("done_u8", E), ("violation", E)]
+        offs, total = {}, 0
+        for name, nbytes in sizes:
+            offs[name] = total
+            total += (nbytes + 15) // 16 * 16
+        self._out_arena = self._alloc((total,), u8)
+        self._out_offsets = offs
+
+        def view(name, nbytes, dtype, shape):
+            return self._out_arena[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
+
+        self.obs = view("obs", E * N * D * 4, f32, (E, N, D))
+        self.reward = view("reward", E * N * 4, f32, (E, N))
+        self.dist_travelled = view("dist_travelled", E * N * 4, f32, (E, N))
+        self.remaining = view("remaining", E * 4, i32, (E,))
+        self.remaining.fill_(-1)
+        self.done_u8 = view("done_u8", E, u8, (E,))
+        self.done = self.done_u8.view(torch.bool)   # the same bytes (the kernel writes 0 / 1): no conversion launch per step
+        self.violation = view("violation", E, u8, (E,))
+
+    def _alloc(self, shape, dtype, fill=0):
+        """One device array (state, output or scratch).  The library never allocates: torch owns the memory."""
+        if fill == 0:
+            return torch.zeros(*shape, dtype=dtype, device=self.device)
+        return torch.full(tuple(shape), fill, dtype=dtype, device=self.device)
 
     # ------------------------------------------------------------------ reference surface
     @property
@@ -219,11 +231,11 @@ class VecRobotariumEnv(object):
         self.time_limit = int(time_limit)
         if self.time_limit < 1:
             raise ValueError("time_limit must be > 0")
-        self.elapsed = torch.zeros(E, dtype=torch.int32, device=dev)
-        self._trunc_u8 = torch.zeros(E, dtype=torch.uint8, device=dev)
-        self._ended_u8 = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self.elapsed = self._alloc((E,), torch.int32)
+        self._trunc_u8 = self._alloc((E,), torch.uint8)
+        self._ended_u8 = self._alloc((E,), torch.uint8)
         self.truncated, self.ended = self._trunc_u8.view(torch.bool), self._ended_u8.view(torch.bool)
-        self.reward_sum = torch.zeros(E, dtype=torch.float32, device=dev)
+        self.reward_sum = self._alloc((E,), torch.float32)
         self._io.elapsed, self._io.truncated = self.elapsed.data_ptr(), self._trunc_u8.data_ptr()
         self._io.ended, self._io.reward_sum = self._ended_u8.data_ptr(), self.reward_sum.data_ptr()
         self._io.time_limit = self.time_limit
@@ -303,15 +315,15 @@ class VecRobotariumEnv(object):
         if tuple(actions.shape) != (K, self.E, self.N):
             raise ValueError(f"actions must be [K,{self.E},{self.N}], got {tuple(actions.shape)}")
         if out is None or out["obs"].shape[0] != K:
-            dev, f32 = self.device, torch.float32
-            out = {"obs": torch.empty(K, self.E, self.N, self.D, dtype=f32, device=dev),
-                   "reward": torch.empty(K, self.E, self.N, dtype=f32, device=dev),
-                   "done": torch.empty(K, self.E, dtype=torch.uint8, device=dev),
-                   "dist_travelled": torch.empty(K, self.E, self.N, dtype=f32, device=dev),
-                   "violation": torch.empty(K, self.E, dtype=torch.uint8, device=dev),
-                   "remaining": torch.empty(K, self.E, dtype=torch.int32, device=dev)}
+            f32, new = torch.float32, self._alloc
+            out = {"obs": new((K, self.E, self.N, self.D), f32),
+                   "reward": new((K, self.E, self.N), f32),
+                   "done": new((K, self.E), torch.uint8),
+                   "dist_travelled": new((K, self.E, self.N), f32),
+                   "violation": new((K, self.E), torch.uint8),
+                   "remaining": new((K, self.E), torch.int32)}
             if self.qp_sweeps is not None:
-                out["qp_sweeps"] = torch.empty(K, self.E, dtype=torch.int32, device=dev)
+                out["qp_sweeps"] = new((K, self.E), torch.int32)
             out["_io"] = _lib.RgStepIO(out["obs"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(),
                                        out["dist_travelled"].data_ptr(), out["violation"].data_ptr(),
                                        out["remaining"].data_ptr(),

@@ -199,8 +199,21 @@ class OracleVecEnv(object):
     def get_state(self, e):
         return {k: getattr(self, k)[e].copy() for k in self.STATE_KEYS}
 
-    def step(self, actions):
+    def step(self, actions, threads=1):
+        """threads > 1: the envs are independent, so contiguous env slices are stepped by a thread pool (the C call
+        releases the GIL) -- used by the parity tests at the BASELINE batch sizes."""
         actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.E, self.N)
+        if threads > 1 and self.E >= 2 * threads:
+            from concurrent.futures import ThreadPoolExecutor
+            cuts = [self.E * i // threads for i in range(threads + 1)]
+            with ThreadPoolExecutor(threads) as pool:
+                list(pool.map(lambda i: self._step_slice(actions, cuts[i], cuts[i + 1]), range(threads)))
+        else:
+            self._step_slice(actions, 0, self.E)
+        return self.obs, self.reward, self.done, {"dist_travelled": self.dist, "violation": self.viol,
+                                                  "remaining": self.remaining}
+
+    def _step_slice(self, actions, lo, hi):
         ct = C.c_double if self.dtype == np.float64 else C.c_float
 
         class St(C.Structure):
@@ -217,18 +230,19 @@ class OracleVecEnv(object):
                         ("dist", C.POINTER(ct)), ("viol", C.POINTER(C.c_uint8)),
                         ("remaining", C.POINTER(C.c_int32)), ("qp_sweeps", C.POINTER(C.c_int32))]
 
-        st = St(_ptr(self.poses, ct), _ptr(self.carry, ct), _ptr(self.steps, C.c_int32), _ptr(self.prey_loc, ct),
-                _ptr(self.prey_sensed, C.c_uint8), _ptr(self.prey_captured, C.c_uint8), _ptr(self.loaded, C.c_uint8),
-                _ptr(self.load, C.c_int32), _ptr(self.zone_load, C.c_int32), _ptr(self.messages, C.c_int32),
-                _ptr(self.grid, C.c_uint8), _ptr(self.goal_col, C.c_int32), _ptr(self.pixel_type, C.c_uint8),
-                _ptr(self.reached_goal, C.c_uint8))
-        out = Out(_ptr(self.obs, ct), _ptr(self.reward, ct), _ptr(self.done, C.c_uint8), _ptr(self.dist, ct),
-                  _ptr(self.viol, C.c_uint8), _ptr(self.remaining, C.c_int32), _ptr(self.qp_sweeps, C.c_int32))
-        rc = self._fn(C.byref(self.p), C.c_int(self.E), C.byref(st), _ptr(actions, C.c_int32), C.byref(out))
+        def sl(a, t):   # the slice's rows of an [E, ...] array (contiguous: the env index is the leading dimension)
+            return _ptr(a[lo:hi], t)
+
+        st = St(sl(self.poses, ct), sl(self.carry, ct), sl(self.steps, C.c_int32), sl(self.prey_loc, ct),
+                sl(self.prey_sensed, C.c_uint8), sl(self.prey_captured, C.c_uint8), sl(self.loaded, C.c_uint8),
+                sl(self.load, C.c_int32), sl(self.zone_load, C.c_int32), sl(self.messages, C.c_int32),
+                sl(self.grid, C.c_uint8), sl(self.goal_col, C.c_int32), sl(self.pixel_type, C.c_uint8),
+                sl(self.reached_goal, C.c_uint8))
+        out = Out(sl(self.obs, ct), sl(self.reward, ct), sl(self.done, C.c_uint8), sl(self.dist, ct),
+                  sl(self.viol, C.c_uint8), sl(self.remaining, C.c_int32), sl(self.qp_sweeps, C.c_int32))
+        rc = self._fn(C.byref(self.p), C.c_int(hi - lo), C.byref(st), sl(actions, C.c_int32), C.byref(out))
         if rc != 0:
             raise RuntimeError(f"orc_step failed: {rc}")
-        return self.obs, self.reward, self.done, {"dist_travelled": self.dist, "violation": self.viol,
-                                                  "remaining": self.remaining}
 
 
 def spec_sincos_f32(t):

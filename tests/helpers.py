@@ -62,3 +62,29 @@ def oracle_reset_params(c_oracle, rg_params):
     rp.zone1_mean, rp.zone1_std = rg_params.zone1_mean, rg_params.zone1_std
     rp.zone2_mean, rp.zone2_std = rg_params.zone2_mean, rg_params.zone2_std
     return rp
+
+
+# the oracle's twin of the device reset sampler, written into row e of an OracleVecEnv (auto-reset of a finished env)
+def oracle_reset(oracle_lib, orc, rp, seed, e, episode):
+    if orc.scenario == "ArcticTransport":
+        p, grid, gc = oracle_lib.reset_arctic_f32(seed, e, episode)
+        orc.poses[e] = p
+        orc.carry[e] = 0
+        orc.steps[e] = 0
+        orc.grid[e] = grid
+        orc.goal_col[e] = gc
+        orc.pixel_type[e] = 0
+        orc.reached_goal[e] = 0
+        return
+    p, q, z = oracle_lib.reset_env_f32(rp, seed, e, episode)
+    orc.poses[e] = p
+    orc.carry[e] = 0
+    orc.steps[e] = 0
+    orc.prey_loc[e] = q[:orc.prey_loc.shape[1]]
+    orc.prey_sensed[e] = 0
+    orc.prey_captured[e] = 0
+    orc.loaded[e] = 0
+    orc.load[e] = 0
+    if orc.scenario == "MaterialTransport":
+        orc.zone_load[e] = z
+        orc.messages[e] = 0

@@ -3,15 +3,17 @@ reference's golden vectors, tier 0, or the float64 oracle, tier 2), teacher-forc
 
     masks (done, violation, remaining, scenario flags / loads)      : bit-exact
     x, y, dist_travelled, rewards, observations                     : <= 1e-5 (north_star), every scenario
-    headings                                                        : <= THETA_MARGIN x the maximum measured for
-                                                                      the fixture (tests/golden/PARITY_REPORT.json)
+    headings                                                        : <= a hand-committed constant per fixture
+                                                                      class (THETA_BOUNDS below; north_star's 1e-5
+                                                                      is NOT met by theta: see theta_bound)
     observation rows over 1e-5                                      : allowed ONLY when explained by a near-tie:
         the row must be built from the same own-observation blocks, and the decision that differs
         (neighbour order / membership, nearest prey, in-sensing-range) must hinge on two float64
         distances closer than TIE_BAND.  Zero unexplained rows.
 
 `python tests/parity.py --write` regenerates tests/golden/PARITY_REPORT.json from the float32 oracle
-(the HIP kernels are bit-identical to it: tests/test_gpu_parity.py::test_step_bit_exact_vs_f32_oracle).
+(the HIP kernels are bit-identical to it: tests/test_gpu_parity.py::test_step_bit_exact_vs_f32_oracle).  The report is a
+RECORD of the measured maxima; no limit is read back from it -- regenerating it cannot change what passes.
 """
 import json
 import os
@@ -19,8 +21,15 @@ import os
 import numpy as np
 
 TOL = 1e-5             # poses, distances, rewards, observations
-THETA_MARGIN = 2.0     # heading bound = THETA_MARGIN x measured maximum of the fixture
-THETA_FLOOR = 1e-6
+# Heading bounds, committed by hand per fixture class (measured maxima at the time of writing in brackets;
+# PARITY_REPORT.json).  theta exceeds north_star's 1e-5 in 9 of the 45 fixtures (max 1.1e-4): a unicycle reversing
+# towards a goal behind it amplifies one ulp of heading ~2.5x per controller period;
+# observations never contain theta, and x, y keep the 1e-5 bar everywhere.
+THETA_BOUNDS = (
+    ("barrier_unsafe", 1.5e-4),   # hand-placed: two robots inside each other's safety radius, 1e6 gain  [1.08e-4]
+    ("long", 8e-5),               # 74 sub-steps per step, or `robotarium: True` (a controller every sub-step)  [5.6e-5]
+    ("default", 4e-5),            # 29 / 36 sub-steps, controller every 15th  [3.2e-5]
+)
 # Two float64 distances closer than this may be ordered either way by the float32 spec: positions agree
 # within ~1.2e-6 (PARITY_REPORT.json), a distance moves by at most |dp_a| + |dp_b| <= 2 sqrt(2) x that.
 # The ties seen in the fixtures are exact float64 ties (robots on the 0.3 m reset grid).
@@ -117,10 +126,17 @@ def load_report():
         return json.load(f)
 
 
-def theta_bound(name):
-    rep = load_report()["fixtures"]
-    assert name in rep, f"{name} is not in PARITY_REPORT.json: run `python tests/parity.py --write`"
-    return max(THETA_MARGIN * rep[name]["max_theta"], THETA_FLOOR)
+def theta_class(name, cfg):
+    if "barrier_unsafe" in name:
+        return "barrier_unsafe"
+    if int(cfg["update_frequency"]) >= 60 or bool(cfg.get("robotarium", False)):
+        return "long"
+    return "default"
+
+
+def theta_bound(name, cfg):
+    """The committed heading bound of a fixture (by its class; nothing measured enters)."""
+    return dict(THETA_BOUNDS)[theta_class(name, cfg)]
 
 
 def check_step_parity(scenario, cfg, name, got, want, theta_limit=None):
@@ -197,7 +213,7 @@ def write_report():
     c_oracle.build_library()
     out = {"what": "float32 spec (oracle tier 3; the HIP kernels are bit-identical to it) against the reference's "
                    "golden vectors (float64, tier 0), teacher-forced per step: measured maxima per fixture",
-           "tolerance": TOL, "theta_margin": THETA_MARGIN, "tie_band": TIE_BAND,
+           "tolerance": TOL, "theta_bounds": dict(THETA_BOUNDS), "tie_band": TIE_BAND,
            "generated_by": "python tests/parity.py --write", "fixtures": {}}
     for path in golden_files():
         g, scenario, cfg = load_golden(path)
@@ -206,7 +222,9 @@ def write_report():
         env.step(g["actions"])
         assert int(env.qp_sweeps.max()) < c_oracle.QP_MAX_SWEEPS["float32"], "a float32 QP hit its sweep cap"
         m = check_step_parity(scenario, cfg, name, oracle_got(env), golden_want(g))
-        m["theta_bound"] = max(THETA_MARGIN * m["max_theta"], THETA_FLOOR)
+        m["theta_class"] = theta_class(name, cfg)
+        m["theta_bound"] = theta_bound(name, cfg)
+        assert m["max_theta"] <= m["theta_bound"], (name, m["max_theta"])
         m["max_qp_sweeps"] = int(env.qp_sweeps.max())
         m["update_frequency"] = int(cfg["update_frequency"])
         out["fixtures"][name] = m

@@ -63,7 +63,7 @@ def test_step_vs_reference_golden(path):
     got = dict(out, poses=post["poses"])
     for k in parity.MASK_KEYS:
         got[k] = post[k]
-    m = parity.check_step_parity(scenario, cfg, name, got, parity.golden_want(g), theta_limit=parity.theta_bound(name))
+    m = parity.check_step_parity(scenario, cfg, name, got, parity.golden_want(g), theta_limit=parity.theta_bound(name, cfg))
     rep = parity.load_report()["fixtures"][name]
     # the kernels are bit-identical to the float32 oracle the report was generated from
     assert m["tie_rows"] == rep["tie_rows"] and abs(m["max_xy"] - rep["max_xy"]) < 1e-12, (m, rep)

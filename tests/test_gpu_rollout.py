@@ -5,7 +5,7 @@ properties at the bench size (4096 envs)."""
 import numpy as np
 import pytest
 
-from helpers import oracle_reset_params
+from helpers import oracle_reset as _oracle_reset, oracle_reset_params
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("step_kernel")]
 
@@ -28,31 +28,6 @@ CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5
          ("ArcticTransport", {}, 5, 200)]
 
 
-def _oracle_reset(oracle_lib, orc, rp, seed, e, episode):
-    if orc.scenario == "ArcticTransport":
-        p, grid, gc = oracle_lib.reset_arctic_f32(seed, e, episode)
-        orc.poses[e] = p
-        orc.carry[e] = 0
-        orc.steps[e] = 0
-        orc.grid[e] = grid
-        orc.goal_col[e] = gc
-        orc.pixel_type[e] = 0
-        orc.reached_goal[e] = 0
-        return
-    p, q, z = oracle_lib.reset_env_f32(rp, seed, e, episode)
-    orc.poses[e] = p
-    orc.carry[e] = 0
-    orc.steps[e] = 0
-    orc.prey_loc[e] = q[:orc.prey_loc.shape[1]]
-    orc.prey_sensed[e] = 0
-    orc.prey_captured[e] = 0
-    orc.loaded[e] = 0
-    orc.load[e] = 0
-    if orc.scenario == "MaterialTransport":
-        orc.zone_load[e] = z
-        orc.messages[e] = 0
-
-
 # ragged and extreme shapes: batch sizes that do not fill a wavefront (1, 7, 65, 130 envs), the
 # smallest and largest agent counts (2, 16), the largest prey count a reset grid of <= 64 cells admits here (54),
 # no neighbours at all, one prey
@@ -66,6 +41,10 @@ EDGE_CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 
                                        "step_dist": 0.16, "num_neighbors": 15}, 5, 40, 9),
               ("Warehouse", {"n_agents": 2, "num_neighbors": 1}, 5, 200, 65),
               ("Warehouse", {"n_agents": 7}, 5, 150, 65),
+              # more neighbour slots than other agents: rows wider than the agents fill (the tail stays zero)
+              ("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "num_neighbors": 5}, 5, 100, 65),
+              ("PredatorCapturePrey", {"predator": 4, "capture": 4, "n_agents": 8, "num_neighbors": 8}, 5, 80, 65),
+              ("Warehouse", {"n_agents": 3}, 5, 150, 65),
               ("MaterialTransport", {}, 20, 100, 65),
               ("Simple", {"n_agents": 2}, 5, 130, 65),
               ("ArcticTransport", {}, 5, 200, 65)]

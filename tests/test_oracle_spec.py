@@ -94,7 +94,7 @@ def test_barrier_qp_is_the_exact_projection(cert, oracle_lib):
         n += 1
     assert n > 100
     assert worst64 < 1e-9, worst64       # sweeps converge to the exact projection
-    assert worst32 < 2e-5, worst32       # float32 tier (rtol 1.25e-6) against float64
+    assert worst32 < 5e-6, worst32       # float32 tier (rtol 1.25e-6) against float64; measured 2.96e-6 (safe), 2.2e-7 (default)
 
 
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
@@ -115,7 +115,7 @@ def test_float32_tier_tracks_float64_tier(path, oracle_lib):
     b.step(g["actions"])
     assert int(b.qp_sweeps.max()) < oracle_lib.QP_MAX_SWEEPS["float32"]
     assert int(a.qp_sweeps.max()) < oracle_lib.QP_MAX_SWEEPS["float64"]
-    lim = parity.theta_bound(name)
+    lim = parity.theta_bound(name, cfg)
     m0 = parity.check_step_parity(scenario, cfg, name, parity.oracle_got(b), parity.golden_want(g), theta_limit=lim)
     parity.check_step_parity(scenario, cfg, name, parity.oracle_got(b), parity.oracle_got(a), theta_limit=lim)
     rep = parity.load_report()["fixtures"][name]
