@@ -237,7 +237,11 @@ __device__ __forceinline__ void fisher_yates2(Lds<GW> &lds, int g, int ag, bool 
     __syncthreads();
 }
 
+// rps: `choices = np.random.choice(x_range * y_range, N, replace=False) + 1`, then `x, y = divmod(c, y_range)`: the
+// sampled index is shifted by one before it is split, so cell (0, 0) is never used and (nx, 0) -- one column past the
+// grid -- is (recalled from upstream rps/utilities/misc.py; unpinned)
 __device__ __forceinline__ void cell_xy(const rg_grid &grid, int cell, float &x, float &y) {
+    cell += 1;
     const int cx = cell / grid.ny, cy = cell - cx * grid.ny;
     const float fx = static_cast<float>(cx) * grid.spacing - grid.w2;
     const float fy = static_cast<float>(cy) * grid.spacing - grid.h2;

@@ -548,4 +548,8 @@ PORTS = {"PredatorCapturePrey": PCPPort, "Warehouse": WarehousePort, "MaterialTr
 
 
 def make_port(scenario, cfg):
+    # the restated simulator's collision test is a module-level switch: follow the config,
+    # as tests/golden/ref_harness.py does for the reference run
+    import rps.robotarium as _rr
+    _rr.COLLISION_VARIANT = cfg.get("collision_variant", "offset")
     return PORTS[scenario](Args(cfg))

@@ -90,7 +90,7 @@ static void sample_cells(draws_t *d, const orc_grid *g, int count, float *outx, 
         uint32_t r = draw_u32(d);
         int j = i + (int)(((uint64_t)r * (uint32_t)(C - i)) >> 32);
         uint8_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
-        int cell = perm[i], cx = cell / g->ny, cy = cell - cx * g->ny;
+        int cell = perm[i] + 1 /* rps: choice(...) + 1 before divmod */, cx = cell / g->ny, cy = cell - cx * g->ny;
         float x = (float)cx * g->spacing - g->w2, y = (float)cy * g->spacing - g->h2;
         outx[i * stride] = (x + g->ox1) + g->ox2;
         outy[i * stride] = (y + g->oy1) + g->oy2;

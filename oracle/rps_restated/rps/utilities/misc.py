@@ -28,7 +28,8 @@ def generate_initial_conditions(N, spacing=0.3, width=3, height=1.8):
     assert x_range != 0, "spacing too large for width"
     assert y_range != 0, "spacing too large for height"
     assert x_range * y_range > N, "too many robots for the grid"
-    choices = np.random.choice(x_range * y_range, N, replace=False)
+    # upstream shifts the sampled indices by one before divmod: cell (0, 0) is never used, (x_range, 0) is
+    choices = (np.random.choice(x_range * y_range, N, replace=False) + 1)
     poses = np.zeros((3, N))
     for i, c in enumerate(choices):
         x, y = divmod(c, y_range)

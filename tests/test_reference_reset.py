@@ -1,8 +1,10 @@
 """Row a17, parity mode: marbler_amd.reference_reset draws initial conditions from a seeded legacy NumPy
 stream with the reference's own call sequence (misc.py:49-63 + rps generate_initial_conditions, scenario
-reset()s).  Pinned by the reference itself: the free-running golden vectors were recorded from
-`Wrapper(seed=s)`, so the pre-step state of the FIRST step of every episode is what the reference's
-reset() produced -- all episodes of all seeds of every fixture must be reproduced, float64-equal."""
+reset()s).  What the reference itself pins is its CALL SEQUENCE: the free-running golden vectors were recorded
+from `Wrapper(seed=s)`, so the pre-step state of the FIRST step of every episode is what the reference's
+reset() produced over the restated rps -- all episodes of all seeds of every fixture must be reproduced,
+float64-equal.  rps' `generate_initial_conditions` itself is the builder's restatement on both sides of this
+comparison (oracle/rps_restated, marbler_amd/reference_reset.py): parity with real rps is unpinned for it."""
 import os
 import random
 
