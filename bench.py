@@ -37,6 +37,18 @@ HEADLINE_KERNEL = "rg::step_kernel<0, 8, false, 5, false"   # <PCP, GW 8, step, 
 SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4     # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2400 MHz, one wave issues a VALU op per 4 cycles
 
 
+def bench_overrides(scenario):
+    """Config overrides of the BASELINE.json configurations: PCP 5 agents (configs[1], [3]),
+    Warehouse 8 agents (configs[2]), MaterialTransport 6 heterogeneous agents (configs[4])."""
+    if scenario == "PredatorCapturePrey":
+        return dict(PCP_OVERRIDES)
+    if scenario == "Warehouse":
+        return {"n_agents": 8}
+    if scenario == "MaterialTransport":
+        return {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}
+    return {}
+
+
 def committed_counters():
     """Per-launch counters of the headline kernel from the COMMITTED rocprofv3 PMC passes of this same command
     (separate --pmc runs; FETCH_SIZE / WRITE_SIZE in KB).  Counters cannot be read from inside an un-profiled
@@ -268,40 +280,60 @@ def launch_ranks(args):
     """`python bench.py --gpus N` without torchrun: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment; one process per GPU, backend nccl unless --dist-backend says otherwise),
     relay rank 0's JSON line, exit non-zero if any rank fails or the rendezvous does not complete.
-    The parent imports neither torch nor HIP: the children are fresh processes, nothing is exec'ed after a GPU
-    has been initialised."""
+    FAIL FAST: all children are polled; the moment any rank exits non-zero the others are killed and that code is
+    returned (a rank that dies before the rendezvous would otherwise leave rank 0 blocked in init_process_group until
+    the time-out).  The time-out (RG_BENCH_LAUNCH_TIMEOUT, default 540 s) stays below the driver's own 600 s, so a
+    stuck node reports an error of this script, not a killed command.
+    The parent imports neither torch nor HIP: the children are fresh processes started before anything touches a GPU,
+    nothing is exec'ed after a GPU has been initialised."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     argv = [a for a in sys.argv[1:]]
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")      # rank 0's stdout (a file: no pipe to drain while polling)
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    deadline = time.time() + float(os.environ.get("RG_BENCH_LAUNCH_TIMEOUT", "900"))
-    rc, line = 0, None
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("RG_BENCH_LAUNCH_TIMEOUT", "540"))
+    rc = 0
     try:
-        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
-        for ln in out0.splitlines():
-            if ln.startswith("{"):
-                line = ln
-        for r, pr in enumerate(procs):
-            code = pr.wait(timeout=max(1.0, deadline - time.time()))
-            if code != 0:
-                print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
-                rc = rc or code
-    except subprocess.TimeoutExpired:
-        print("bench.py: ranks did not finish in time", file=sys.stderr)
-        rc = 4
+        while True:
+            codes = [pr.poll() for pr in procs]
+            failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if failed:
+                for r, c in failed:
+                    print(f"bench.py: rank {r} exited with {c}; stopping the other ranks", file=sys.stderr)
+                rc = failed[0][1] if failed[0][1] > 0 else 1      # a signal (negative code) reports as 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                print("bench.py: ranks did not finish in time", file=sys.stderr)
+                rc = 4
+                break
+            time.sleep(0.05)
     finally:
         for pr in procs:                        # exactly the processes started above
             if pr.poll() is None:
                 pr.kill()
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+    out0.seek(0)
+    line = None
+    for ln in out0.read().splitlines():
+        if ln.startswith("{"):
+            line = ln
+    out0.close()
     if rc == 0 and line is None:
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
         rc = 5
@@ -319,8 +351,8 @@ def dry_run(args, rank, world, collective):
     from marbler_amd import dist as rgdist
     from marbler_amd.params import params_to_bytes
     E = args.envs_per_gpu
-    ov = PCP_OVERRIDES if rank == 0 else {}                      # only rank 0 holds the benchmark's overrides
-    params = make_params(args.scenario, load_config(args.scenario, overrides=ov))
+    # only rank 0 holds the benchmark's overrides; the others build the scenario's default block and receive rank 0's
+    params = make_params(args.scenario, load_config(args.scenario, overrides=bench_overrides(args.scenario) if rank == 0 else {}))
     if world > 1:
         params = rgdist.broadcast_params(params, src=0, device="cpu")
     offset, count = rgdist.shard(world * E, rank, world)
@@ -375,6 +407,11 @@ def main():
               f"for a different number of ranks", file=sys.stderr)
         sys.exit(2)
 
+    if os.environ.get("RG_BENCH_FAULT_RANK") == os.environ.get("RANK", "0") and "WORLD_SIZE" in os.environ:
+        # fault injection for the launcher test (tests/test_host.py): this rank dies before the rendezvous
+        print(f"bench.py: rank {os.environ.get('RANK')} told to fail (RG_BENCH_FAULT_RANK)", file=sys.stderr)
+        sys.exit(7)
+
     # The CPU baseline runs first, while this process has not touched the GPU: it starts child
     # processes (one env each on the host cores), and nothing is exec'ed after HIP is initialised.
     cpu_ref = None
@@ -409,9 +446,7 @@ def main():
     E = args.envs_per_gpu
     K, W = args.steps, args.warmup
 
-    overrides = PCP_OVERRIDES if args.scenario == "PredatorCapturePrey" else \
-        {"n_agents": 8} if args.scenario == "Warehouse" else \
-        {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}
+    overrides = bench_overrides(args.scenario)
     # rank 0 reads the YAML; every rank gets the parameter block by RCCL broadcast
     params = make_params(args.scenario, load_config(args.scenario, overrides=overrides)) if rank == 0 else None
     if grouped:

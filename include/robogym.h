@@ -130,8 +130,9 @@ typedef struct rg_state {
      * snapshot): an env's NEXT initial state, drawn ahead of time at the end of a launch in which the env did not finish,
      * so that the launch in which it does finish copies it instead of running the sampler on its critical path.
      * next_init: [E][rg_next_init_stride(params)] floats; next_episode: [E], the episode index (= reset_count) the block
-     * was drawn for, -1 = none.  Initialise next_episode to -1.  The library invalidates the blocks itself when the
-     * `seed` argument of rg_step / rg_rollout changes. */
+     * was drawn for, -1 = none.  The library marks every block stale itself (next_episode <- -1, one memset on the
+     * handle's stream) on the first rg_step / rg_rollout after rg_bind_state and whenever their `seed` argument changes;
+     * a caller that rewrites state arrays behind the handle's back (restoring a snapshot) resets next_episode to -1. */
     float *next_init;
     int32_t *next_episode;
 } rg_state;

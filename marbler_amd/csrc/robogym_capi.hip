@@ -205,6 +205,9 @@ int rg_bind_state(rg_handle *h, const rg_state *st) {
     if (reinterpret_cast<uintptr_t>(st->next_init) & 15u) return fail(-26, "next_init must be 16-byte aligned");
     h->state = *st;
     h->bound = true;
+    // whatever the rebound next_init / next_episode arrays hold was not drawn by this handle under a seed it knows:
+    // the first rg_step / rg_rollout after a bind marks every block stale (sync_seed), whatever the caller put there
+    h->seed_seen = false;
     return 0;
 }
 
@@ -226,10 +229,10 @@ static int fill_args(rg_handle *h, rg::KernelArgs &a) {
 // The blocks of rg_state.next_init are functions of (seed, global env, episode): a new seed makes them stale.
 static int sync_seed(rg_handle *h, uint64_t seed) {
     if (h->state.next_episode && (!h->seed_seen || h->last_seed != seed)) {
-        if (h->seed_seen) {
-            const hipError_t err = hipMemsetAsync(h->state.next_episode, 0xFF, sizeof(int32_t) * static_cast<size_t>(h->num_envs), h->stream);
-            if (err != hipSuccess) return fail(-30, "hipMemsetAsync(next_episode) failed: %s", hipGetErrorString(err));
-        }
+        // first use after rg_bind_state, or a new seed: every tag <- -1 (one 4 E-byte memset on the stream; the caller's
+        // initialisation of next_episode is not trusted)
+        const hipError_t err = hipMemsetAsync(h->state.next_episode, 0xFF, sizeof(int32_t) * static_cast<size_t>(h->num_envs), h->stream);
+        if (err != hipSuccess) return fail(-30, "hipMemsetAsync(next_episode) failed: %s", hipGetErrorString(err));
         h->seed_seen = true;
         h->last_seed = seed;
     }

@@ -38,11 +38,15 @@ class GymmaVecEnv(object):
     """E envs behind gymma's method names; everything is a device tensor with a leading E axis."""
 
     def __init__(self, key, num_envs, time_limit, config_path=None, overrides=None, device="cuda:0", seed=0,
-                 env_offset=0, fused=True):
+                 env_offset=0, fused=True, alias_outputs=False):
         """fused: gym's TimeLimit and the gymma reductions run inside the env's step launch (VecRobotariumEnv.
         enable_time_limit): step() is ONE launch.  fused=False composes them from torch ops around the step (a dozen
-        launches; kept as the readable statement of the contract and as the check of the fused path)."""
+        launches; kept as the readable statement of the contract and as the check of the fused path).
+        alias_outputs: step() returns the env's persistent output buffers themselves (reward sum, terminated,
+        TimeLimit.truncated) instead of copies -- three small copy launches less per step, but the NEXT step overwrites
+        what the previous one returned; only for callers that consume a step's outputs before stepping again."""
         self.fused = bool(fused)
+        self.alias_outputs = bool(alias_outputs)
         self.scenario = scenario_from_key(key)
         self.env = VecRobotariumEnv(self.scenario, num_envs, config_path=config_path, overrides=overrides,
                                     device=device, seed=seed, env_offset=env_offset, auto_reset=True,
@@ -71,13 +75,19 @@ class GymmaVecEnv(object):
     def step(self, actions):
         """actions [E, N] int -> (reward [E] f32 = sum over agents, terminated [E] bool, info).
         Envs that terminate (scenario rule or time limit) start a new episode; their next observation
-        is the reset observation (zeros, as the reference returns from reset())."""
+        is the reset observation (zeros, as the reference returns from reset()).
+        reward, terminated and info["TimeLimit.truncated"] are fresh tensors (a runner may keep step t's while it
+        takes step t + 1) unless the env was built with alias_outputs=True; the other info entries (dist_travelled,
+        violation, remaining) are always views of the env's output buffers, valid until the next step."""
         obs, reward, done, info = self.env.step(actions)
         if self.fused:      # everything below happened inside that one launch
             self._obs, self._ended = None, self.env.ended
             out = dict(info)
-            out["TimeLimit.truncated"] = self.env.truncated
-            return self.env.reward_sum, self.env.ended, out
+            if self.alias_outputs:
+                out["TimeLimit.truncated"] = self.env.truncated
+                return self.env.reward_sum, self.env.ended, out
+            out["TimeLimit.truncated"] = self.env.truncated.clone()
+            return self.env.reward_sum.clone(), self.env.ended.clone(), out
         self._elapsed += 1
         truncated = (self._elapsed >= self.episode_limit) & ~done          # gym TimeLimit
         ended = done | truncated

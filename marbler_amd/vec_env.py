@@ -266,6 +266,7 @@ class VecRobotariumEnv(object):
         if self.E != 1:
             raise ValueError("host_step is the single-env path (num_envs == 1)")
         import numpy as np
+        self._sync_stream()     # the launch, the upload and the download below all go to torch's CURRENT stream
         if getattr(self, "_hs", None) is None:
             o, N, D = self._out_offsets, self.N, self.D
             host = torch.zeros_like(self._out_arena, device="cpu").pin_memory()
@@ -357,6 +358,18 @@ class VecRobotariumEnv(object):
         return sd
 
     def load_state_dict(self, sd):
+        """Restore a snapshot.  The TimeLimit counter (`elapsed`) travels with snapshots of time-limited envs: a
+        time-limited env REQUIRES it (a stale counter would move the next truncation), an env without a time limit
+        refuses a snapshot that carries one (it would be dropped silently)."""
+        if self.elapsed is not None and "elapsed" not in sd:
+            raise KeyError("snapshot has no 'elapsed' (gym TimeLimit counter) but this env has a time limit: take the "
+                           "snapshot from a time-limited env, or add sd['elapsed'] (zeros = every episode just started)")
+        if self.elapsed is None and "elapsed" in sd:
+            raise KeyError("snapshot carries 'elapsed' (gym TimeLimit counter) but this env has no time limit: call "
+                           "enable_time_limit() first, or drop the key")
+        unknown = [k for k in sd if k != "seed" and k != "elapsed" and k not in self.STATE_KEYS]
+        if unknown:
+            raise KeyError(f"unknown snapshot keys {unknown}")
         if self.next_episode is not None:
             self.next_episode.fill_(-1)     # drawn-ahead initial states belong to the state that is being replaced
         for k, v in sd.items():

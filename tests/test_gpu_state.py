@@ -73,6 +73,19 @@ def test_snapshot_of_a_time_limited_env_keeps_the_time_limit_counter(step_kernel
         assert torch.equal(b.ended, e) and torch.equal(b.truncated, tr) and torch.equal(b.reward_sum.view(torch.int32), rs.view(torch.int32)), t
     assert torch.equal(a.elapsed, b.elapsed) and torch.equal(a.poses.view(torch.int32), b.poses.view(torch.int32))
     assert int(sum(int(x[1].sum()) for x in ends_a)) > 0       # the limit did fire
+    # the counter is part of the contract in both directions: no silent drop, no stale counter
+    c = VecRobotariumEnv("PredatorCapturePrey", 128, overrides=ov, seed=5)          # no time limit
+    with pytest.raises(KeyError, match="elapsed"):
+        c.load_state_dict(snap)
+    c.load_state_dict({k: v for k, v in snap.items() if k != "elapsed"})            # dropping it explicitly is fine
+    plain = {k: v.cpu() for k, v in c.state_dict().items()}
+    assert "elapsed" not in plain
+    with pytest.raises(KeyError, match="elapsed"):
+        b.load_state_dict(plain)                                                    # time-limited env needs the counter
+    b.load_state_dict(dict(plain, elapsed=torch.zeros(128, dtype=torch.int32)))
+    assert int(b.elapsed.abs().sum()) == 0
+    with pytest.raises(KeyError, match="unknown"):
+        c.load_state_dict({"no_such_array": torch.zeros(1)})
 
 
 def test_explicit_reset_restarts_the_running_return_and_can_book_the_episode(step_kernel):

@@ -211,3 +211,34 @@ def test_fused_time_limit_equals_the_composed_gymma_step(kernel, key, ov, n_act,
     assert n_done > E // 2 and (n_trunc > E if limit < 50 else n_trunc == 0)
     a.close()
     b.close()
+
+
+def test_gymma_step_outputs_survive_the_next_step():
+    """A runner appends step t's reward / terminated tensors to a list while it takes step t + 1 (EPyMARL's episode
+    batch): the fused step must hand out fresh tensors, not views of the buffers the next launch overwrites.  With
+    alias_outputs=True the views themselves are returned (documented), and the list then repeats the last step."""
+    import torch
+    from marbler_amd.gymma import GymmaVecEnv
+    key, ov, E, T = "robotarium_gym:PredatorCapturePrey-v0", {"predator": 3, "capture": 2, "n_agents": 5}, 128, 40
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(9)
+    acts = torch.randint(0, 5, (T, E, 5), generator=g, device="cuda:0", dtype=torch.int32)
+    kept = {}
+    for alias in (False, True):
+        env = GymmaVecEnv(key, E, time_limit=12, overrides=ov, seed=2, fused=True, alias_outputs=alias)
+        env.reset()
+        rows = [env.step(acts[t]) for t in range(T)]
+        kept[alias] = (torch.stack([r[0] for r in rows]), torch.stack([r[1] for r in rows]),
+                       torch.stack([r[2]["TimeLimit.truncated"] for r in rows]))
+        env.close()
+    ref = GymmaVecEnv(key, E, time_limit=12, overrides=ov, seed=2, fused=False)   # composed contract: always fresh tensors
+    ref.reset()
+    rows = [ref.step(acts[t]) for t in range(T)]
+    want = (torch.stack([r[0] for r in rows]), torch.stack([r[1] for r in rows]),
+            torch.stack([r[2]["TimeLimit.truncated"] for r in rows]))
+    ref.close()
+    assert torch.allclose(kept[False][0], want[0], rtol=0, atol=1e-5)
+    assert torch.equal(kept[False][1], want[1]) and torch.equal(kept[False][2], want[2])
+    assert int(want[1].sum()) > 0 and int(want[2].sum()) > 0
+    # the aliasing form: every kept entry is the same buffer = the last step
+    assert torch.equal(kept[True][1], want[1][-1:].expand_as(want[1]))

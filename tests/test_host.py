@@ -241,6 +241,42 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     assert d["params_sha1"] == hashlib.sha1(params_to_bytes(want)).hexdigest() and d["config"]["agents"] == 5
 
 
+@pytest.mark.parametrize("scenario,envs,ov", [
+    ("Warehouse", 4096, {"n_agents": 8}),                                                                   # configs[2]
+    ("MaterialTransport", 2048, {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}),  # configs[4]
+    ("PredatorCapturePrey", 4096, {"predator": 3, "capture": 2, "n_agents": 5})])                           # configs[3]
+def test_bench_other_baseline_configs_have_a_rehearsed_multi_rank_command_line(scenario, envs, ov):
+    """`python bench.py --gpus N --scenario S --envs-per-gpu E` for BASELINE configs[2]-[4], rehearsed with two ranks on gloo."""
+    import hashlib
+    import json
+    from marbler_amd import load_config, make_params
+    from marbler_amd.params import params_to_bytes
+    r = _run_bench("--gpus", "2", "--dist-backend", "gloo", "--dry-run", "--scenario", scenario, "--envs-per-gpu", str(envs))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    want = make_params(scenario, load_config(scenario, overrides=ov))
+    assert d["n_gpus"] == 2 and d["gathered_envs"] == 2 * envs and d["config"]["agents"] == want.n_agents
+    assert d["params_sha1"] == hashlib.sha1(params_to_bytes(want)).hexdigest()
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies_before_the_rendezvous():
+    """Rank 1 exits before init_process_group: rank 0 would wait for it until the store times out.  The launcher polls
+    every child, kills the survivors and returns the failed rank's code within seconds."""
+    import time
+    t0 = time.time()
+    r = _run_bench("--gpus", "2", "--dist-backend", "gloo", "--dry-run", env={"RG_BENCH_FAULT_RANK": "1"})
+    took = time.time() - t0
+    assert r.returncode == 7, (r.returncode, r.stderr[-1000:])
+    assert "rank 1 exited with 7" in r.stderr
+    assert took < 60, f"the launcher took {took:.0f} s to notice a dead rank"
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_timeout_is_below_the_drivers():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'RG_BENCH_LAUNCH_TIMEOUT", "540"' in src
+
+
 def test_bench_refuses_a_rank_count_it_was_not_started_with():
     r = _run_bench("--gpus", "8", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
