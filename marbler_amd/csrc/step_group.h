@@ -569,6 +569,9 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                 static_for<0, C>([&](auto UU) {
                     constexpr int u = decltype(UU)::value;
                     dmin_u[u] = 0x7FFFFFFF;
+#ifdef RG_PROBE_NO_PAIRTEST  // probe build only (WRONG results: collisions go unseen): the launch without the pair pre-test,
+                    return;  // an upper bound on what any cheaper collision pre-test could save (tools/perf_probe.py --set pairtest)
+#endif
                     auto test = [&](int partner_q) {
                         const half2v dq = __builtin_bit_cast(half2v, q[u]) - __builtin_bit_cast(half2v, partner_q);
                         const int d2 = dot2_bits(dq);

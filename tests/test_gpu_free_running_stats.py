@@ -1,0 +1,31 @@
+"""Free-running statistical equivalence, GPU tier ("drop-in for training"): the HIP kernels stepping 4096 envs x 400 steps
+under a random policy against the float64 C oracle (the reference's arithmetic) started from the same reset stream with
+the same actions.  Trajectories part wherever float32 rounding flips a threshold -- expected; the distributions a trainer
+sees (episode lengths, returns, violation codes, what is left at episode end) agree within 3 sigma of the sampling error.
+The oracle's statistics are the committed record tests/golden/FREE_RUNNING_STATS.json (tests/free_running.py --write); the
+kernels must ALSO reproduce the float32 oracle's statistics of that record exactly (they are bit-identical to it).
+
+Reference: utilities/misc.py:134-221 (run_env statistics)."""
+import json
+import os
+
+import pytest
+
+import free_running as fr
+
+pytestmark = pytest.mark.gpu
+RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "FREE_RUNNING_STATS.json")
+
+
+@pytest.mark.parametrize("kernel", ["group", "tpe"])
+@pytest.mark.parametrize("name", sorted(fr.CASES))
+def test_kernels_match_the_float64_oracle_statistically(name, kernel, monkeypatch):
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
+    scenario, ov, n_act, E, steps = fr.CASES[name]
+    rec = json.load(open(RECORD))["cases"][name]
+    got = fr.run_gpu(scenario, ov, E, steps, n_act, fr.SEED, fr.ACTION_SEED)
+    fr.compare(got, rec["float64"], f"{name} ({kernel} kernel) vs float64 oracle")
+    # bit-identical to the float32 oracle => identical statistics (returns are summed in float64 on both sides)
+    for key in ("episodes", "env_steps", "length_hist", "violation_counts", "remaining_hist"):
+        assert got[key] == rec["float32"][key], (name, key)
+    assert abs(got["return_mean"] - rec["float32"]["return_mean"]) < 1e-9

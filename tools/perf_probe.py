@@ -110,6 +110,28 @@ if __name__ == "__main__":
                          ({"penalize_violations": False}, True), ({}, False)):
             r = probe("PredatorCapturePrey", 524288, steps=40, warm=40, auto_reset=ar, **over)
             print(json.dumps(r), flush=True)
+    if args.set == "pairtest":   # headline / MaterialTransport / Warehouse launches and the multi-step launch, for A/B runs of
+        # the shipped library against the -DRG_PROBE_NO_PAIRTEST build (ROBOGYM_LIB=marbler_amd/librobogym_nopair.so)
+        os.environ["RG_STEP_KERNEL"] = "group"
+        for scn, E in (("PredatorCapturePrey", 4096), ("MaterialTransport", 2048), ("MaterialTransport", 4096), ("Warehouse", 4096),
+                       ("PredatorCapturePrey", 32768), ("MaterialTransport", 32768)):
+            r = probe(scn, E, steps=400, warm=100)
+            r["lib"] = os.environ.get("ROBOGYM_LIB", "shipped")
+            print(json.dumps(r), flush=True)
+        for scn, E, nact in (("PredatorCapturePrey", 4096, 5), ("MaterialTransport", 2048, 20)):
+            env = VecRobotariumEnv(scn, E, overrides=OV[scn])
+            env.reset()
+            acts = torch.randint(0, nact, (64, E, env.N), device=env.device, dtype=torch.int32)
+            buf = env.rollout(acts)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(8):
+                env.rollout(acts, out=buf)
+            b.record()
+            torch.cuda.synchronize()
+            print(json.dumps({"scenario": scn, "E": E, "api": "rg_rollout K=64", "us_per_step": a.elapsed_time(b) * 1e3 / (8 * 64),
+                              "lib": os.environ.get("ROBOGYM_LIB", "shipped")}), flush=True)
     if args.set == "big":     # one saturated configuration (for rocprofv3 --pmc runs); RG_STEP_KERNEL picks the kernel
         out.append(probe("PredatorCapturePrey", 524288, steps=20, warm=10))
     for r in out:
