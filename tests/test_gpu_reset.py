@@ -105,11 +105,14 @@ def test_reset_geometry_and_state(scenario, ov):
     cy = (P[:, 1] - g.oy1 - g.oy2 + g.h2) / g.spacing
     assert np.abs(cx - np.round(cx)).max() < 1e-4 and np.abs(cy - np.round(cy)).max() < 1e-4
     cx, cy = np.round(cx).astype(int), np.round(cy).astype(int)
-    assert cx.min() >= 0 and cx.max() < g.nx and cy.min() >= 0 and cy.max() < g.ny
+    # rps: choices = np.random.choice(nx * ny, N, replace=False) + 1, then divmod(c, ny): indices 1 .. nx * ny, i.e.
+    # cell (0, 0) is never used and (nx, 0), one column past the grid, is
+    assert cx.min() >= 0 and cx.max() <= g.nx and cy.min() >= 0 and cy.max() < g.ny
     cell = cx * g.ny + cy
+    assert cell.min() == 1 and cell.max() == g.nx * g.ny
     assert all(len(set(row)) == env.N for row in cell)          # distinct cells (replace=False)
-    # every cell is used, roughly uniformly
-    counts = np.bincount(cell.ravel(), minlength=g.nx * g.ny)
+    # every index is used, roughly uniformly
+    counts = np.bincount(cell.ravel() - 1, minlength=g.nx * g.ny)
     expect = E * env.N / (g.nx * g.ny)
     assert counts.min() > 0.8 * expect and counts.max() < 1.2 * expect
     if scenario == "Warehouse":
