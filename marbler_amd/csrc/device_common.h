@@ -78,12 +78,40 @@ __device__ __forceinline__ float cross_lane(float v) {
 }
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-// bits of d.x*d.x + d.y*d.y in binary32 (VOP3P v_dot2_f32_f16 with a literal-zero addend; the
-// compiler's own selection is v_dot2c, which costs an extra v_mov to clear the accumulator)
-__device__ __forceinline__ int dot2_bits(half2v d) {
-    int r;
-    asm("v_dot2_f32_f16 %0, %1, %1, 0" : "=v"(r) : "v"(d));
-    return r;
+// d[i] <- bits of d[i].x * d[i].x + d[i].y * d[i].y in binary32, i < K: VOP3P v_dot2_f32_f16 with a literal-zero addend
+// (the compiler's own selection for __builtin_amdgcn_fdot2 is v_dot2c, which costs an extra v_mov to clear the
+// accumulator), issued as ONE inline-asm block that ends in `s_nop 2`.
+// HAZARD (gfx940 / gfx950): a VALU instruction that reads the destination of a DOT instruction needs 3 wait states
+// after it; the hardware does not interlock, and the compiler's hazard recogniser cannot see into inline asm (for its
+// own v_dot2c it emits exactly this s_nop 2).  With a bare `asm("v_dot2_f32_f16 ...")` a consumer scheduled within
+// three instructions of the dot reads the register's OLD contents -- the packed binary16 difference itself.  Rounds 1-2
+// shipped that form and were correct only because the scheduler happened to issue 20 dots back to back ahead of their
+// first consumer; the first restructuring of the pre-test (round 3) put a v_min two instructions behind a dot and every
+// chunk went to the exact replay.  The block below is safe wherever it is scheduled: later dots of the block are the
+// wait states of the earlier ones, the s_nop covers the last.
+template <int K>
+__device__ __forceinline__ void dot2_batch(int (&d)[K]) {
+    static_assert(K >= 1, "at least one");
+    if constexpr (K >= 4) {
+        asm("v_dot2_f32_f16 %0, %0, %0, 0\n\tv_dot2_f32_f16 %1, %1, %1, 0\n\tv_dot2_f32_f16 %2, %2, %2, 0\n\t"
+            "v_dot2_f32_f16 %3, %3, %3, 0\n\ts_nop 2"
+            : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+        if constexpr (K > 4) {
+            int rest[K - 4];
+#pragma unroll
+            for (int i = 0; i < K - 4; ++i) rest[i] = d[4 + i];
+            dot2_batch<K - 4>(rest);
+#pragma unroll
+            for (int i = 0; i < K - 4; ++i) d[4 + i] = rest[i];
+        }
+    } else if constexpr (K == 3) {
+        asm("v_dot2_f32_f16 %0, %0, %0, 0\n\tv_dot2_f32_f16 %1, %1, %1, 0\n\tv_dot2_f32_f16 %2, %2, %2, 0\n\ts_nop 2"
+            : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
+    } else if constexpr (K == 2) {
+        asm("v_dot2_f32_f16 %0, %0, %0, 0\n\tv_dot2_f32_f16 %1, %1, %1, 0\n\ts_nop 2" : "+v"(d[0]), "+v"(d[1]));
+    } else {
+        asm("v_dot2_f32_f16 %0, %0, %0, 0\n\ts_nop 2" : "+v"(d[0]));
+    }
 }
 
 template <int I, int END, typename F>

@@ -15,6 +15,7 @@ struct Consts {
     float dt, pd, inv_pd, r2, wlim, vmax, wmax, pvl, bml;
     float xmin, xmax, ymin, ymax, coll_off, coll_lim2;
     float thr_pre;         // collision pre-test: threshold on the squared distance of the binary16-rounded points
+    float lin_pre;         // the same threshold as a distance (collision limit + rounding bound): the sparse pre-test widens it by travel
     float xc, xh, yc, yh;  // boundary pre-test: arena centre and half extents
 };
 
@@ -26,6 +27,11 @@ struct Consts {
 //    distance by sqrt(2) times the per-axis error; `pre_margin` is that bound with 5 % on top.
 //  * boundary: a robot moves at most |dt v| (1 + 1e-6) per sub-step, so all pre-update positions of a
 //    chunk of C sub-steps lie within (C-1) |dt v| of the first; the test is |x - xc| + margin > xh.
+//  * sparse collision pre-test (lane-group kernel): inside a controller period a robot's collision point moves at
+//    most m = (|dt v| + coll_off |dt w|)(1 + 1e-5) per sub-step (the body's Euler step, plus the chord of the heading
+//    change times the offset), so |f_i(u) - f_j(u)| >= |f_i(u0) - f_j(u0)| - 2 (u - u0) max(m): one test of sub-step u0
+//    against lin_pre + 2 span max(m) stands for sub-steps u0 .. u0 + span.  Valid while the widened threshold stays
+//    below 0.24 m (the binary16 difference is then below 0.25 m per axis, where its own rounding is <= 2^-14 m).
 constexpr float PRE_SLACK = 2e-6f;  // roundings of the position updates and of xc / xh
 inline float pre_margin(float max_abs_coordinate) {
     float spacing = 0.0009765625f;  // 2^-10: binary16 spacing in [1, 2)
@@ -55,6 +61,7 @@ inline Consts make_consts(const rg_scenario_params &p) {
     const float ax = fmaxf(fabsf(k.xmin), fabsf(k.xmax)), ay = fmaxf(fabsf(k.ymin), fabsf(k.ymax));
     const float lp = lim + pre_margin(fmaxf(ax, ay) + 0.25f);  // robots that left the arena fire the boundary test
     k.thr_pre = lp * lp * 1.00001f;
+    k.lin_pre = lp;
     k.xc = 0.5f * (k.xmin + k.xmax);
     k.xh = 0.5f * (k.xmax - k.xmin);
     k.yc = 0.5f * (k.ymin + k.ymax);

@@ -513,6 +513,9 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
         const int ghost_q = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(1000.0f + 32.0f * ag, -1000.0f));
         float v = 0.0f, w = 0.0f, s = 0.0f, c = 1.0f;
+#ifdef RG_STAMPS_CHUNK
+        int chunk_ticks[4] = {0, 0, 0, 0};  // ticks in the dense pre-test, ticks in the replay, dense chunks, replayed chunks
+#endif
         float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
         bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
         float fin_x = 0.0f, fin_y = 0.0f;
@@ -541,6 +544,22 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             const float mrg = __builtin_fmaf((CHUNK - 1) * 1.000001f, __builtin_fabsf(dtv), PRE_SLACK);
             int n_exec = n;             // sub-steps this env executes in this period
             bool died_now = false;
+            // SPARSE collision pre-test (kernel_args.h): v and w are constant inside the period, so between two sub-steps
+            // a robot's collision point moves at most |dt v| (the body) + coll_off |dt w| (the chord of its turn) per
+            // sub-step.  A test of sub-step u against a threshold widened by the travel of BOTH robots over `span` further
+            // sub-steps (2 span M, M = the group's largest per-sub-step travel) covers sub-steps u .. u + span: a pair that
+            // passes it cannot be within the collision distance at any of them.  A chunk tests sub-steps 0 (covering 0..2)
+            // and 3 (covering the rest) instead of all five; only a chunk that fails goes on to the per-sub-step pre-test
+            // and, from there, to the exact replay -- the masks come from the exact test alone, results are unchanged.
+            const float mstep = lane_ok ? __builtin_fmaf(k.coll_off, __builtin_fabsf(dtw), __builtin_fabsf(dtv)) * 1.00001f : 0.0f;
+            const float M2 = 2.0f * group_max_nonneg<GW>(mstep);
+            auto thr_span = [&](int span) {  // bits of the squared threshold (non-negative floats order like their bit patterns)
+                const float t = (k.lin_pre + PRE_SLACK) + static_cast<float>(span) * M2;
+                return __builtin_bit_cast(int, (t * t) * 1.00002f);
+            };
+            const int thr_s1 = thr_span(1), thr_s2 = thr_span(2);
+            // the binary16 rounding bound behind lin_pre holds for differences below 0.25 m per axis
+            const bool sparse_ok = (k.lin_pre + 2.0f * M2) < 0.24f;
 
             // C sub-steps starting at sub-step j0 of this period
             auto run_chunk = [&](auto CC, int j0) {
@@ -565,34 +584,68 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     c = cn;
                     s = sn;
                 });
-                int dmin_u[C];  // per sub-step: the replay runs the exact pair test only where the pre-test fired
-                static_for<0, C>([&](auto UU) {
-                    constexpr int u = decltype(UU)::value;
-                    dmin_u[u] = 0x7FFFFFFF;
-#ifdef RG_PROBE_NO_PAIRTEST  // probe build only (WRONG results: collisions go unseen): the launch without the pair pre-test,
-                    return;  // an upper bound on what any cheaper collision pre-test could save (tools/perf_probe.py --set pairtest)
-#endif
-                    auto test = [&](int partner_q) {
-                        const half2v dq = __builtin_bit_cast(half2v, q[u]) - __builtin_bit_cast(half2v, partner_q);
-                        const int d2 = dot2_bits(dq);
-                        dmin_u[u] = d2 < dmin_u[u] ? d2 : dmin_u[u];
+                // smallest squared distance (bits) between this lane's rounded collision point and its partners'
+                auto pair_min = [&](int qv) {
+                    // the pre-test may visit the pairs in any order.  5 <= N <= 7 in groups of 8: the three quad rounds
+                    // cover the pairs inside each quad, then each agent of the upper quad (4 .. N-1) is broadcast over
+                    // its quad and mirrored onto the lower one: 3 + (N-4) rounds instead of 7
+                    constexpr bool QUAD_COVER = GW == 8 && NT >= 5 && NT <= 7;
+                    constexpr int R = QUAD_COVER ? NT - 1 : GW - 1;
+                    int d[R];
+                    auto diff = [&](int partner_q) {
+                        return __builtin_bit_cast(int, __builtin_bit_cast(half2v, qv) - __builtin_bit_cast(half2v, partner_q));
                     };
-                    if constexpr (GW == 8 && NT >= 5 && NT <= 7) {
-                        // the pre-test may visit the pairs in any order: the three quad rounds cover the
-                        // pairs inside each quad, then each agent of the upper quad (4 .. N-1) is broadcast
-                        // over its quad and mirrored onto the lower one: 3 + (N-4) rounds instead of 7
-                        static_for<1, 4>([&](auto KK) { test(xor_lane_i<decltype(KK)::value>(q[u])); });
-                        static_for<0, NT - 4>([&](auto MM) {
-                            constexpr int M = decltype(MM)::value;
-                            test(cross_lane_i<M>(q[u]));
-                        });
+                    if constexpr (QUAD_COVER) {
+                        static_for<1, 4>([&](auto KK) { d[decltype(KK)::value - 1] = diff(xor_lane_i<decltype(KK)::value>(qv)); });
+                        static_for<0, NT - 4>([&](auto MM) { d[3 + decltype(MM)::value] = diff(cross_lane_i<decltype(MM)::value>(qv)); });
                     } else {
-                        static_for<1, GW>([&](auto KK) { test(xor_lane_i<decltype(KK)::value>(q[u])); });
+                        static_for<1, GW>([&](auto KK) { d[decltype(KK)::value - 1] = diff(xor_lane_i<decltype(KK)::value>(qv)); });
                     }
+                    int dm = 0x7FFFFFFF;
+#ifdef RG_PROBE_NO_PAIRTEST  // probe build only (WRONG results: collisions go unseen): the launch without the pair pre-test,
+                    return dm;  // an upper bound on what any cheaper collision pre-test could save (tools/perf_probe.py --set pairtest)
+#endif
+                    dot2_batch<R>(d);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dm = d[r] < dm ? d[r] : dm;
+                    return dm;
+                };
+                // sparse pre-test: sub-step 0 covers 0 .. min(2, C-1), sub-step 3 the rest of the chunk; a chunk that fails
+                // adds the remaining sub-steps (the dense pre-test of rounds 1-2: every sub-step against the unwidened
+                // threshold), so a failing chunk costs what every chunk used to cost
+                int dmin_u[C];  // per sub-step: the replay runs the exact pair test only where the pre-test fired
+                bool sparse_hit = live & !sparse_ok;
+                {
+                    constexpr int SPAN0 = C - 1 < 2 ? C - 1 : 2;
+                    const int t0 = SPAN0 == 0 ? thr_pre : SPAN0 == 1 ? thr_s1 : thr_s2;
+                    dmin_u[0] = pair_min(q[0]);
+                    sparse_hit = sparse_hit | (dmin_u[0] <= t0);
+                    if constexpr (C >= 4) {
+                        const int t3 = C == 4 ? thr_pre : thr_s1;
+                        dmin_u[3] = pair_min(q[3]);
+                        sparse_hit = sparse_hit | (dmin_u[3] <= t3);
+                    }
+                }
+#ifdef RG_DENSE_PRETEST  // diagnostic build: every chunk takes the dense pre-test (A/B runs against rounds 1-2)
+                sparse_hit = live;
+#endif
+                if (penalize && __any(sparse_hit | bnd_any)) {
+#ifdef RG_STAMPS_CHUNK  // diagnostic: ticks inside the dense pre-test (slot 0) and inside the exact replay (slot 1), summed over the step
+                const unsigned long long t_dense0 = __builtin_amdgcn_s_memtime();
+#endif
+                static_for<1, C>([&](auto UU) {
+                    constexpr int u = decltype(UU)::value;
+                    if constexpr (u != 3) dmin_u[u] = pair_min(q[u]);
                 });
                 int dmin = dmin_u[0];
                 static_for<1, C>([&](auto UU) { dmin = dmin_u[decltype(UU)::value] < dmin ? dmin_u[decltype(UU)::value] : dmin; });
-                if (penalize && __any((dmin <= thr_pre) | bnd_any)) {
+#ifdef RG_STAMPS_CHUNK
+                asm volatile("" ::"v"(dmin));
+                const unsigned long long t_dense1 = __builtin_amdgcn_s_memtime();
+                chunk_ticks[0] += static_cast<int>(t_dense1 - t_dense0);
+                chunk_ticks[2] += 1;
+#endif
+                if (__any((dmin <= thr_pre) | bnd_any)) {
                     replayed = true;
                     // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94): the
                     // boundary test on every sub-step (per lane, cheap), the pair rounds only on the sub-steps
@@ -643,6 +696,12 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                         rc = cn;
                         rs = sn;
                     });
+#ifdef RG_STAMPS_CHUNK
+                    asm volatile("" ::"v"(rx), "v"(ry));
+                    chunk_ticks[1] += static_cast<int>(__builtin_amdgcn_s_memtime() - t_dense1);
+                    chunk_ticks[3] += 1;
+#endif
+                }
                 }
             };
             int j = 0;
@@ -675,6 +734,11 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         dist = viol ? acc : acc - last;
         carry = last;
         RG_STAMP(3);  // all periods done
+#ifdef RG_STAMPS_CHUNK
+        stamps[0] = chunk_ticks[0];
+        stamps[1] = chunk_ticks[1];
+        stamps[2] = chunk_ticks[2] * 1000 + chunk_ticks[3];
+#endif
     }
 
     // ---- scenario epilogue

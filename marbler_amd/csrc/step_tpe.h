@@ -559,12 +559,15 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #pragma unroll
                 for (int i = 0; i < N; ++i)
                     q[i] = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(k.coll_off, c[i], x[i]), __builtin_fmaf(k.coll_off, s[i], y[i])));
+                int dd[N * (N - 1) / 2];  // the sub-step's pair differences, squared as one hazard-safe batch (device_common.h)
+                int np = 0;
                 for_pairs<N>([&](auto II, auto JJ) {
                     constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
-                    const half2v dq = q[i] - q[j];
-                    const int d2 = dot2_bits(dq);
-                    dmin = d2 < dmin ? d2 : dmin;
+                    dd[np++] = __builtin_bit_cast(int, q[i] - q[j]);
                 });
+                dot2_batch<N * (N - 1) / 2>(dd);
+#pragma unroll
+                for (int r = 0; r < N * (N - 1) / 2; ++r) dmin = dd[r] < dmin ? dd[r] : dmin;
                 advance(x, y, ox, oy, c, s);
             });
             if (penalize && ((dmin <= thr_pre) | bnd_any)) {

@@ -71,3 +71,61 @@ def test_diagnostic_builds_of_the_thread_per_env_kernel_still_compile():
     and only built by hand: one compile with all of them keeps the macros from rotting."""
     rep = _report("tpe_pcp5.hip", defines=("RG_STAMPS", "RG_STAMPS_EPI", "RG_TPE_GUARD", "RG_TPE_DIAG"))
     assert len(rep) == 3
+
+
+def _asm(src):
+    from marbler_amd import build as hip_build
+    try:
+        hipcc = hip_build.hipcc_path()
+    except RuntimeError:
+        pytest.skip("no hipcc")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "-S",
+                            "--cuda-device-only", os.path.join(ROOT, "tests", "kernels", src), "-o", out],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return open(out).read()
+
+
+def _regs(operand_text):
+    """VGPR numbers mentioned in an operand list: v12, v[4:7]."""
+    regs = set()
+    for m in re.finditer(r"\bv(\d+)\b", operand_text):
+        regs.add(int(m.group(1)))
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return regs
+
+
+@pytest.mark.parametrize("src", ["group_pcp5.hip", "tpe_pcp5.hip"])
+def test_no_instruction_touches_a_dot_result_within_three_wait_states(src):
+    """gfx940 / gfx950 do not interlock a VALU read (or overwrite) of a DOT instruction's destination: it needs three
+    wait states, which the compiler cannot provide for `v_dot2_f32_f16` issued from inline asm (csrc/device_common.h
+    dot2_batch ends every block in `s_nop 2` for that reason).  A consumer closer than that reads the register's OLD
+    contents -- silently: the collision pre-test would compare garbage.  Checked on the compiler's own output for the
+    benchmark instantiations of both step kernels."""
+    text = _asm(src)
+    lines = [ln.split(";")[0].strip() for ln in text.splitlines()]
+    insts = [ln for ln in lines if ln and not ln.startswith((".", "#")) and not ln.endswith(":")]
+    n_dots = 0
+    for i, ln in enumerate(insts):
+        m = re.match(r"v_dot2_f32_f16\s+v(\d+)\s*,", ln)
+        if not m:
+            continue
+        n_dots += 1
+        dst, waited, j = int(m.group(1)), 0, i + 1
+        while waited < 3 and j < len(insts):
+            nxt = insts[j]
+            op = nxt.split(None, 1)
+            assert not (op[0].startswith("s_cbranch") or op[0] in ("s_branch", "s_endpgm", "s_setpc_b64")), \
+                f"control flow {waited} wait states after `{ln}`: the s_nop of its block is missing"
+            if op[0] == "s_nop":
+                waited += int(op[1], 0) + 1
+            else:
+                assert dst not in _regs(op[1] if len(op) > 1 else ""), \
+                    f"`{nxt}` touches v{dst} {waited} wait states after `{ln}` (needs 3)"
+                waited += 1
+            j += 1
+    assert n_dots > 50, "the pre-test's dot instructions were not found: the check looks at nothing"

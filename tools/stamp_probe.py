@@ -5,7 +5,7 @@ library) and prints per-phase wave-cycle shares (s_memtime ticks).  Build it fir
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["ROBOGYM_LIB"] = os.path.join(ROOT, "marbler_amd", "librobogym_stamps.so")
+os.environ["ROBOGYM_LIB"] = os.environ.get("RG_STAMPS_LIB") or os.path.join(ROOT, "marbler_amd", "librobogym_stamps.so")
 sys.path.insert(0, ROOT)
 import torch
 from marbler_amd import VecRobotariumEnv
