@@ -31,9 +31,14 @@ ALGO_BYTES_OTHER = {"Warehouse": 896, "MaterialTransport": 510}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-PMC_PROFILE = os.path.join("profiles", "r2_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
-PMC_FALLBACKS = (os.path.join("profiles", "r2a_xcd_pmc_summary.csv"), os.path.join("profiles", "r1_final_pmc_summary.csv"))
+PMC_PROFILE = os.path.join("profiles", "r3_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
+PMC_FALLBACKS = (os.path.join("profiles", "r2_final_pmc_summary.csv"), os.path.join("profiles", "r2a_xcd_pmc_summary.csv"))
 HEADLINE_KERNEL = "rg::step_kernel<0, 8, false, 5, false"   # <PCP, GW 8, step, N 5, single launch[, no gymma block]>
+HEADLINE_GRID = 1024 * 64                                     # 4096 envs at 4 per wavefront: 1024 one-wave workgroups
+# rocprofv3's FETCH_SIZE on gfx950 reports half the bytes read, in every access shape of the step kernels (4 B per lane,
+# 16 B per lane, the strided 60-byte pose blocks); WRITE_SIZE is exact (1.01 for 1-byte flags): measured on known byte
+# counts past the Infinity Cache, tools/ubench/hbm_calib.py -> profiles/r3_hbm_calibration.csv
+FETCH_SIZE_SCALE, WRITE_SIZE_SCALE = 2.0, 1.0
 SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 4     # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md: 2400 MHz, one wave issues a VALU op per 4 cycles
 
 
@@ -58,7 +63,7 @@ def committed_counters():
         try:
             vals = {}
             for r in csv.DictReader(open(os.path.join(ROOT, rel))):
-                if HEADLINE_KERNEL in r["kernel"]:
+                if HEADLINE_KERNEL in r["kernel"] and int(r.get("grid_work_items") or HEADLINE_GRID) == HEADLINE_GRID:
                     vals[r["counter"]] = float(r["mean_per_launch"])
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                 return vals, rel
@@ -517,7 +522,7 @@ def main():
         achieved = bytes_per_launch / (gpu_ms_total / K * 1e-3) / 1e9 if bytes_per_launch else None
         counters, counters_src = committed_counters() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU) \
             else ({}, None)
-        traffic = (counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0 if counters else None
+        traffic = (FETCH_SIZE_SCALE * counters["FETCH_SIZE"] + WRITE_SIZE_SCALE * counters["WRITE_SIZE"]) * 1024.0 if counters else None
         kernel_s = gpu_ms_total / K * 1e-3
         valu = None
         if "SQ_INSTS_VALU" in counters:
@@ -537,7 +542,10 @@ def main():
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_kind": "from_committed_profile (rocprofv3 --pmc passes of this command; not measured in this run)",
+                         "traffic_kind": "from_committed_profile (rocprofv3 --pmc passes of this command; not measured in this run): "
+                                         "2 x FETCH_SIZE + WRITE_SIZE, the factors calibrated on known byte counts in the kernels' own "
+                                         "access shapes (profiles/r3_hbm_calibration.csv); ~0.36 MB of it is the kernel's own "
+                                         "instructions, fetched by each of the 8 XCD L2s per launch (profiles/r3_fetch_floor_pmc_summary.csv)",
                          "traffic_source": counters_src, "valu": valu,
                          "kernel": (f"rg::step_kernel<{args.scenario},GW={4 if N <= 4 else 8 if N <= 8 else 16},N={N}> (lane group per env)"
                                     if (args.scenario != "PredatorCapturePrey" or E < 53248)

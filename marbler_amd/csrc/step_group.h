@@ -42,10 +42,24 @@ constexpr int CHUNK = RG_CHUNK;
 // ------------------------------------------------------------------ controller (a3..a8)
 // utilities/controller.py:20-24 over the restated rps closures,
 // followed by Robotarium.set_velocities' clipping.  Called in wave-uniform control flow.
+#ifdef RG_STAMPS_CTRL  // diagnostic (-DRG_STAMPS -DRG_STAMPS_CTRL): ticks per controller part, summed over the step's controllers
+#define RG_CTRL_TICK(i)                                                     \
+    {                                                                       \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        ctrl_ticks[i] += static_cast<int>(t_ - ctrl_t);                     \
+        ctrl_t = t_;                                                        \
+    }
+#else
+#define RG_CTRL_TICK(i)
+#endif
 template <int GW>
 __device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, int N, int ag, bool lane_ok,
                                           bool upd, float x, float y, float c, float s, float gx, float gy, float &v,
-                                          float &w) {
+                                          float &w, int *ctrl_ticks = nullptr) {
+#ifdef RG_STAMPS_CTRL
+    asm volatile("" ::"v"(x), "v"(y), "v"(c), "v"(s));
+    unsigned long long ctrl_t = __builtin_amdgcn_s_memtime();
+#endif
     // a4 uni_to_si_states, a5 si_position_controller (gain 1, |dxi| <= 0.15)
     const float xix = x + k.pd * c, xiy = y + k.pd * s;
     float ux = gx - xix, uy = gy - xiy;
@@ -84,6 +98,11 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         emax[K - 1] = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
         mu[K - 1] = muA[K - 1] = muB[K - 1] = 0.0f;
     });
+#ifdef RG_STAMPS_CTRL
+#pragma unroll
+    for (int r_ = 0; r_ < GW - 1; ++r_) asm volatile("" ::"v"(fx[r_]), "v"(bp[r_]), "v"(emax[r_]));
+#endif
+    RG_CTRL_TICK(0);  // position controller + pair constants
     {   // "Threshold control inputs before QP": decided on squares; never taken after the 0.15 clip
         const float n2u = ux * ux + uy * uy;
         const bool clip = n2u > k.bml * k.bml;
@@ -155,6 +174,10 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         if (!__any(active)) break;
         sweep(std::integral_constant<int, 0>{});
     }
+#ifdef RG_STAMPS_CTRL
+    asm volatile("" ::"v"(ux), "v"(uy));
+#endif
+    RG_CTRL_TICK(1);  // sweeps
     // a7 si_to_uni_dyn, a8 set_velocities
     float vv = c * ux + s * uy;
     float ww = k.inv_pd * (-s * ux + c * uy);
@@ -166,6 +189,11 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     ww = ww < -k.wmax ? -k.wmax : ww;
     v = upd ? vv : v;
     w = upd ? ww : w;
+#ifdef RG_STAMPS_CTRL
+    asm volatile("" ::"v"(v), "v"(w));
+    ctrl_ticks[3] += sweeps;
+#endif
+    RG_CTRL_TICK(2);  // si -> uni, clips
     return my_sweeps;
 }
 
@@ -516,6 +544,9 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 #ifdef RG_STAMPS_CHUNK
         int chunk_ticks[4] = {0, 0, 0, 0};  // ticks in the dense pre-test, ticks in the replay, dense chunks, replayed chunks
 #endif
+#ifdef RG_STAMPS_CTRL
+        int ctrl_ticks[5] = {0, 0, 0, 0, 0};  // set-up, sweeps, tail, wave-level sweep count, heading sin/cos
+#endif
         float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
         bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
         float fin_x = 0.0f, fin_y = 0.0f;
@@ -527,8 +558,17 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         const int U = p.update_frequency, period = p.controller_period;
         for (int it0 = 0; it0 < U; it0 += period) {
             const int n = (U - it0) < period ? (U - it0) : period;
+#ifdef RG_STAMPS_CTRL
+            asm volatile("" ::"v"(th));
+            const unsigned long long t_sc = __builtin_amdgcn_s_memtime();
+            sincos_spec(th, s, c);
+            asm volatile("" ::"v"(s), "v"(c));
+            ctrl_ticks[4] += static_cast<int>(__builtin_amdgcn_s_memtime() - t_sc);
+            const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w, ctrl_ticks);
+#else
             sincos_spec(th, s, c);
             const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w);
+#endif
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
             const float dtv = k.dt * v, dtw = k.dt * w;
             float sd, cd;
@@ -734,6 +774,12 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         dist = viol ? acc : acc - last;
         carry = last;
         RG_STAMP(3);  // all periods done
+#ifdef RG_STAMPS_CTRL
+        stamps[0] = ctrl_ticks[0];
+        stamps[1] = ctrl_ticks[1];
+        stamps[2] = ctrl_ticks[2] * 100 + ctrl_ticks[3];   // tail ticks x 100 + sweeps the wave executed
+        stamps[3] = ctrl_ticks[4];
+#endif
 #ifdef RG_STAMPS_CHUNK
         stamps[0] = chunk_ticks[0];
         stamps[1] = chunk_ticks[1];

@@ -26,8 +26,10 @@ if [[ " $* " != *" nopmc "* ]]; then
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1 || { tail -20 $OUT/pmc_fetch.log; exit 4; }
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $BENCH > $OUT/pmc_write.log 2>&1 || { tail -20 $OUT/pmc_write.log; exit 5; }
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $BENCH > $OUT/pmc_sq.log 2>&1 || { tail -20 $OUT/pmc_sq.log; exit 6; }
-  find $OUT -name "*.csv" | head -30
-  # keep the merge small: drop the raw kernel trace (stats are kept)
-  find $OUT/kt -name "*kernel_trace.csv" -size +20M -delete
+  # condensed on the box (the rocpd databases are too large to merge back): $OUT/summ/<tag>_{kernel_stats,pmc_summary}.csv
+  python3 tools/summarize_rocpd.py $TAG --outdir $OUT/summ --stats $(find $OUT/kt -name "*.db") --pmc fetch=$(find $OUT/pmc_fetch -name "*.db") \
+      --pmc write=$(find $OUT/pmc_write -name "*.db") --pmc sq=$(find $OUT/pmc_sq -name "*.db") > /dev/null || exit 8
+  rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+  grep "step_kernel" $OUT/summ/${TAG}_kernel_stats.csv | cut -c1-160
 fi
 echo JOB_DONE
