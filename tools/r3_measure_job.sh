@@ -36,6 +36,17 @@ if has configs; then
   prof mt_2048x6 --scenario MaterialTransport --envs-per-gpu 2048 --steps 1000
   prof warehouse_4096x8 --scenario Warehouse --steps 1000
   prof mt_4096x6 --scenario MaterialTransport --steps 1000
+  prof pcp_32768x5 --envs-per-gpu 32768 --steps 1000
+fi
+
+if has driver; then   # the driver's own command line (20 timed steps after 5 warm-up steps), three times
+  for i in 1 2 3; do timeout -k 10 200 python3 bench.py --gpus 1 --steps 20 --warmup 5 >> $OUT/driver_like.jsonl 2>> $OUT/driver_like.err || { tail -5 $OUT/driver_like.err; exit 9; }; done
+  python3 -c "
+import json
+for l in open('$OUT/driver_like.jsonl'):
+    if l.startswith('{'):
+        d = json.loads(l); print('driver-like: %.4g agent-steps/s, %.2f us/step, kernel %.2f us' % (d['value'], d['ms_per_step'] * 1e3, d['roofline']['kernel_ms_avg'] * 1e3))
+"
 fi
 
 if has stamps; then
