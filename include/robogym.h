@@ -216,6 +216,12 @@ int rg_set_stream(rg_handle *h, void *hip_stream);
  * where get_obs() lives).  obs: [E][N][D]. */
 int rg_get_obs(rg_handle *h, float *obs);
 
+/* Which step kernel this handle launches: 0 = lane group per env (small / medium batches, N >= 7), 1 = one lane per env
+ * (chip-filling batches).  Chosen in rg_create from (scenario, n_agents, num_envs) -- measured cross-overs, csrc/robogym_capi.hip
+ * tpe_min_envs -- or forced by the environment variable RG_STEP_KERNEL=group|tpe.  Both give bit-identical results; the
+ * query exists so that tests and profiles can say which one ran.  Negative: error. */
+int rg_step_kernel(const rg_handle *h);
+
 /* ---- policy inference for evaluation rollouts ------------------------
  * The EPyMARL recurrent actor the reference evaluates with (utilities/rnn_agent.py:5-29 `RNNAgent`:
  * fc1 -> ReLU -> GRUCell -> fc2; utilities/rnn_ns_agent.py:5-36 `RNNNSAgent`: one per agent), for all

@@ -80,7 +80,7 @@ class RgActorWeights(C.Structure):
 
 
 EXPORTS = ("rg_abi_version", "rg_last_error", "rg_sizeof_params", "rg_sizeof_state", "rg_sizeof_step_io", "rg_next_init_stride",
-           "rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs",
+           "rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs", "rg_step_kernel",
            "rg_actor_forward", "rg_actor_pack_gru", "rg_actor_last_error")
 
 _lib = None
@@ -116,6 +116,8 @@ def load():
     lib.rg_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RgStepIO), C.c_int32, C.c_uint64]
     lib.rg_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(RgStepIO), C.c_int32, C.c_uint64]
     lib.rg_get_obs.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rg_step_kernel.argtypes = [C.c_void_p]
+    lib.rg_step_kernel.restype = C.c_int
     lib.rg_actor_forward.argtypes = [C.POINTER(RgActorWeights), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rg_actor_forward.restype = C.c_int

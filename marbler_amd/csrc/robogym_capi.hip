@@ -28,15 +28,21 @@ struct rg_handle {
 };
 
 // Which step kernel: both give identical results.  The lane-group kernel has the shorter chain for
-// small batches; the thread-per-env kernel takes over once the batch fills the chip.  Measured
-// cross-overs on MI355X (tools/crossover_probe.py): N = 5 at ~52k envs,
-// the others at ~64k (N = 6 since it runs two waves per SIMD: in every scenario);
-// for N >= 7 the per-lane register footprint (28 pairs) leaves one wave per SIMD and the lane-group
-// kernel stays ahead.  RG_STEP_KERNEL=group|tpe forces one (tests, profiling).
+// small batches and is linear in the batch; the thread-per-env kernel's time is a step function of how many
+// generations of wavefronts the batch needs (65 536 envs per generation and wave slot per SIMD), so it takes
+// over where one of its steps undercuts the line.  Measured cross-overs on MI355X, final kernels of round 3
+// (tools/crossover_probe.py, gpurun_out/r3_crossover*.txt): the sparse collision pre-test made
+// the lane-group kernel 5-8 % faster at these batch sizes and moved every threshold up from round 2's 53 248 / 65 536.
+// For N >= 7 the per-lane register footprint (28 pairs) leaves one wave per SIMD and the lane-group kernel -- at
+// 92 % VALU issue there -- stays ahead at every batch size.  RG_STEP_KERNEL=group|tpe forces one (tests, profiling).
 static int32_t tpe_min_envs(const rg_scenario_params &p) {
+    const bool mt = p.scenario == RG_SCN_MATERIAL_TRANSPORT, pcp = p.scenario == RG_SCN_PREDATOR_CAPTURE_PREY;
     switch (p.n_agents) {
-        case 2: case 3: case 4: case 6: return 65536;
-        case 5: return 53248;
+        case 2: return 65536;
+        case 3: return pcp ? 98304 : 65536;
+        case 4: return (p.scenario == RG_SCN_SIMPLE || p.scenario == RG_SCN_ARCTIC_TRANSPORT) ? 393216 : 196608;
+        case 5: return mt ? 49152 : 65536;
+        case 6: return mt ? 98304 : 131072;
         default: return INT32_MAX;
     }
 }
@@ -316,6 +322,11 @@ int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg
         if (int rc = launched(rg::launch_step_tpe(ak, h->stream))) return rc;
     }
     return 0;
+}
+
+int rg_step_kernel(const rg_handle *h) {
+    if (!h) return fail(-1, "handle is NULL");
+    return h->use_tpe ? 1 : 0;
 }
 
 int rg_get_obs(rg_handle *h, float *obs) {

@@ -288,6 +288,12 @@ class VecRobotariumEnv(object):
         torch.cuda.current_stream(self.device).synchronize()
         return hs["obs"], hs["reward"], bool(hs["done"][0]), int(hs["viol"][0]), int(hs["remaining"][0]), hs["dist"]
 
+    @property
+    def step_kernel(self):
+        """'group' (a lane group per env) or 'tpe' (one lane per env): the kernel this env's handle launches
+        (robogym_capi.hip: tpe_min_envs; RG_STEP_KERNEL forces one).  Results are bit-identical either way."""
+        return "tpe" if self.lib.rg_step_kernel(self._h) == 1 else "group"
+
     def step_raw(self, actions_ptr):
         """Hot-loop entry: one rg_step on a pre-validated device pointer to int32 [E,N]; results are
         in self.obs / reward / done_u8 / dist_travelled / violation / remaining.  Launches on the stream of

@@ -172,33 +172,49 @@ def test_step_is_deterministic_and_shard_invariant():
     assert torch.equal(full.done_return_sum, torch.cat([lo.done_return_sum, hi.done_return_sum]))
 
 
-def test_large_batch_dispatch_matches_lane_group_kernel(monkeypatch):
-    """At 49152 envs the library picks the thread-per-env kernel on its own (robogym_capi.hip);
-    every output and the whole state must equal the lane-group kernel's, bit for bit, over steps
-    that include auto-resets."""
+@pytest.mark.parametrize("scenario,ov,n_act,E,auto_kernel", [
+    ("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 65536, "tpe"),    # the threshold itself
+    ("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 61440, "group"),  # just below it
+    ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}, 20, 98304, "tpe"),
+    ("Warehouse", {"n_agents": 8}, 5, 65536, "group")])                                        # N >= 7: always the lane-group kernel
+def test_large_batch_dispatch_matches_lane_group_kernel(scenario, ov, n_act, E, auto_kernel, monkeypatch):
+    """The library's own kernel choice at large batches (robogym_capi.hip: tpe_min_envs; `rg_step_kernel` says which one
+    a handle launches) and the thread-per-env kernel forced, against the lane-group kernel forced: every output and the
+    whole state bit for bit, over steps that include auto-resets.  Warehouse 65536 x 8: the thread-per-env N = 8
+    instantiation is never picked, but it exists and must agree."""
     import torch
     from marbler_amd import VecRobotariumEnv
-    E, ov = 49152, {"predator": 3, "capture": 2, "n_agents": 5}
     monkeypatch.delenv("RG_STEP_KERNEL", raising=False)
-    auto = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov, seed=5)
+    auto = VecRobotariumEnv(scenario, E, overrides=ov, seed=5)
+    assert auto.step_kernel == auto_kernel
+    monkeypatch.setenv("RG_STEP_KERNEL", "tpe")
+    tpe = VecRobotariumEnv(scenario, E, overrides=ov, seed=5)
+    assert tpe.step_kernel == "tpe"
     monkeypatch.setenv("RG_STEP_KERNEL", "group")
-    ref = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov, seed=5)
+    ref = VecRobotariumEnv(scenario, E, overrides=ov, seed=5)
+    assert ref.step_kernel == "group"
     g = torch.Generator(device=auto.device)
     g.manual_seed(2)
-    auto.reset()
-    ref.reset()
+    envs = (auto, tpe, ref)
+    for env in envs:
+        env.reset()
     for t in range(40):
-        a = torch.randint(0, 5, (E, 5), generator=g, device=auto.device, dtype=torch.int32)
-        o1, r1, d1, i1 = auto.step(a)
-        o2, r2, d2, i2 = ref.step(a)
-        assert torch.equal(o1.view(torch.int32), o2.view(torch.int32))
-        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2)
-        for k in i1:
-            assert torch.equal(i1[k], i2[k]), k
-    s1, s2 = auto.state_dict(), ref.state_dict()
-    for k in s1:
-        assert torch.equal(s1[k], s2[k]), k
+        a = torch.randint(0, n_act, (E, auto.N), generator=g, device=auto.device, dtype=torch.int32)
+        outs = [env.step(a) for env in envs]
+        o2, r2, d2, i2 = outs[2]
+        for o1, r1, d1, i1 in outs[:2]:
+            assert torch.equal(o1.view(torch.int32), o2.view(torch.int32)), t
+            assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(d1, d2), t
+            for k in i1:
+                assert torch.equal(i1[k], i2[k]), (t, k)
+    s2 = ref.state_dict()
+    for env in (auto, tpe):
+        s1 = env.state_dict()
+        for k in s1:
+            assert torch.equal(s1[k], s2[k]), k
     assert int(auto.done_count.sum()) > 0
+    for env in envs:
+        env.close()
 
 
 @pytest.mark.parametrize("scenario,ov,n_act,E", [

@@ -5,15 +5,22 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from marbler_amd import VecRobotariumEnv
-CFG = {4: [("PredatorCapturePrey", {"predator": 2, "capture": 2, "n_agents": 4}, 5), ("MaterialTransport", {}, 20)],
-       5: [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5)],
+CFG = {2: [("PredatorCapturePrey", {"predator": 1, "capture": 1, "n_agents": 2, "num_neighbors": 1}, 5), ("Simple", {"n_agents": 2}, 5),
+           ("Warehouse", {"n_agents": 2, "num_neighbors": 1}, 5)],
+       3: [("PredatorCapturePrey", {"predator": 2, "capture": 1, "n_agents": 3}, 5), ("Warehouse", {"n_agents": 3}, 5)],
+       4: [("PredatorCapturePrey", {"predator": 2, "capture": 2, "n_agents": 4}, 5), ("MaterialTransport", {}, 20),
+           ("Simple", {}, 5), ("ArcticTransport", {}, 5), ("Warehouse", {"n_agents": 4}, 5)],
+       5: [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5), ("Warehouse", {"n_agents": 5}, 5),
+           ("MaterialTransport", {"n_agents": 5, "n_fast_agents": 3, "n_slow_agents": 2, "start_dist": 0.25}, 20), ("Simple", {"n_agents": 5}, 5)],
        6: [("PredatorCapturePrey", {"predator": 3, "capture": 3, "n_agents": 6}, 5),
            ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}, 20),
-           ("Warehouse", {"n_agents": 6}, 5)],
-       3: [("PredatorCapturePrey", {"predator": 2, "capture": 1, "n_agents": 3}, 5)]}
+           ("Warehouse", {"n_agents": 6}, 5), ("Simple", {"n_agents": 6}, 5)]}
+ONLY = os.environ.get("RG_CROSS_ONLY")   # e.g. "Simple,ArcticTransport": restrict to these scenarios
 for N in [int(v) for v in sys.argv[1:]] or [6]:
     for scn, ov, nact in CFG[N]:
-        for E in (16384, 24576, 32768, 49152, 65536, 98304, 131072, 196608):
+        if ONLY and scn not in ONLY.split(","):
+            continue
+        for E in (32768, 49152, 65536, 81920, 98304, 131072, 163840, 196608, 262144, 393216):
             row = []
             for kern in ("group", "tpe"):
                 os.environ["RG_STEP_KERNEL"] = kern
