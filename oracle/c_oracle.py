@@ -33,7 +33,7 @@ class OrcParams(C.Structure):
         ("position_velocity_limit", C.c_double),
         ("barrier_gain", C.c_double), ("unsafe_barrier_gain", C.c_double), ("safety_radius", C.c_double),
         ("barrier_magnitude_limit", C.c_double), ("qp_rtol", C.c_double), ("qp_max_sweeps", C.c_int32),
-        ("pad_", C.c_int32),
+        ("qp_mode", C.c_int32),
         ("left", C.c_double), ("right", C.c_double), ("up", C.c_double), ("down", C.c_double),
         ("agent_step", C.c_double * MAXN), ("sensing_radius", C.c_double * MAXN),
         ("capture_radius", C.c_double * MAXN),
@@ -75,6 +75,9 @@ def params_from_config(scenario, cfg, collision_variant="offset", dtype=np.float
     p = OrcParams()
     p.qp_rtol = cfg.get("qp_rtol", QP_RTOL[np.dtype(dtype).name])
     p.qp_max_sweeps = cfg.get("qp_max_sweeps", QP_MAX_SWEEPS[np.dtype(dtype).name])
+    if cfg.get("qp_solver", "exact") == "cvxopt_restated":   # study mode (float64 tier): oracle_core.h barrier_qp_ipm
+        assert np.dtype(dtype) == np.float64, "the interior-point study mode exists in the float64 tier only"
+        p.qp_mode, p.qp_rtol, p.qp_max_sweeps = 1, cfg.get("cvxopt_reltol", 1e-2), cfg.get("cvxopt_maxiters", 50)
     p.scenario = SCN[scenario]
     p.update_frequency = int(cfg["update_frequency"])
     p.controller_period = 1 if cfg.get("robotarium", False) else 15   # roboEnv.py:63

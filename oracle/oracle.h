@@ -32,7 +32,9 @@ typedef struct orc_params {
     double projection_distance, angular_velocity_limit, position_velocity_limit;
     double barrier_gain, unsafe_barrier_gain, safety_radius, barrier_magnitude_limit;
     double qp_rtol;               /* Hildreth stop: max change <= qp_rtol * max(|u|_inf, magnitude_limit) */
-    int32_t qp_max_sweeps, pad_;
+    int32_t qp_max_sweeps;
+    int32_t qp_mode;              /* 0: the exact projection (sim_spec_v0).  1, float64 tier only: study mode, a restated cvxopt
+                                     interior-point iterate at qp_rtol = reltol = feastol, qp_max_sweeps = maxiters (oracle_core.h) */
     /* scenario */
     double left, right, up, down;
     double agent_step[ORC_MAXN];      /* step_dist, or MaterialTransport per-agent speed */

@@ -272,6 +272,192 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
     return sweeps;
 }
 
+#if !ORC_IS_F32
+/* STUDY MODE (qp_mode == 1, float64 tier only; never part of a parity claim): the barrier QP solved the way the
+ * reference's rps hands it to cvxopt -- `solvers.qp(H, f, A, b)` with H = 2I, f = -2 vec(uhat), rows
+ * A[c, 2i:2i+2] = -2 e_ij, A[c, 2j:2j+2] = +2 e_ij, b[c] = gamma h^3 and
+ * `options['reltol'] = options['feastol'] = 1e-2, maxiters = 50` -- by a restatement, FROM MEMORY, of cvxopt's coneqp for
+ * the linear cone (cvxopt is absent from this image: unpinned): default starting point from the least-squares KKT
+ * system, Mehrotra predictor-corrector with Nesterov-Todd scaling (for the linear cone: the plain s, z iteration),
+ * step 0.99 to the boundary, sigma = (1 - step + dsdz/gap step^2)^3, stop when pres, dres <= feastol and
+ * (gap <= abstol or relgap <= reltol).  Its iterate is an APPROXIMATE, strictly interior solution; how far it sits from
+ * the exact projection, and what that does to the statistics a trainer sees, is what tests/free_running.py measures
+ * with it. */
+static int FN(chol_solve)(int n, REAL *M, REAL *b) { /* M (n x n, row-major, SPD) <- its Cholesky factor; b <- M^-1 b */
+    for (int j = 0; j < n; ++j) {
+        REAL d = M[j * n + j];
+        for (int k = 0; k < j; ++k) d -= M[j * n + k] * M[j * n + k];
+        if (!(d > R(0))) return -1;
+        d = SQRT(d);
+        M[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            REAL v = M[i * n + j];
+            for (int k = 0; k < j; ++k) v -= M[i * n + k] * M[j * n + k];
+            M[i * n + j] = v / d;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        REAL v = b[i];
+        for (int k = 0; k < i; ++k) v -= M[i * n + k] * b[k];
+        b[i] = v / M[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        REAL v = b[i];
+        for (int k = i + 1; k < n; ++k) v -= M[k * n + i] * b[k];
+        b[i] = v / M[i * n + i];
+    }
+    return 0;
+}
+
+#define ORC_MAXV (2 * ORC_MAXN)
+#define ORC_MAXC (ORC_MAXN * (ORC_MAXN - 1) / 2)
+static int FN(barrier_qp_ipm)(const orc_params *p, int N, const REAL *xix, const REAL *xiy, REAL *ux, REAL *uy) {
+    const int n = 2 * N;
+    int m = 0;
+    static const REAL ABSTOL = 1e-7, STEP = 0.99;
+    const REAL RELTOL = p->qp_rtol > 0 ? p->qp_rtol : 1e-2, FEASTOL = RELTOL;
+    const int MAXITERS = p->qp_max_sweeps > 0 ? p->qp_max_sweeps : 50;
+    REAL r2 = R(p->safety_radius) * R(p->safety_radius);
+    /* rows in rps' order (i < j, i outer); vec(u) column-major: u[2a] = x of robot a, u[2a+1] = y */
+    static _Thread_local REAL G[ORC_MAXC][ORC_MAXV];
+    REAL h[ORC_MAXC];
+    for (int i = 0; i < N - 1; ++i)
+        for (int j = i + 1; j < N; ++j) {
+            REAL dx = xix[i] - xix[j], dy = xiy[i] - xiy[j];
+            REAL hh = dx * dx + dy * dy - r2;
+            REAL gain = (hh >= 0 || !p->barrier_has_unsafe_gain) ? p->barrier_gain : p->unsafe_barrier_gain;
+            for (int k = 0; k < n; ++k) G[m][k] = 0;
+            G[m][2 * i] = -2 * dx; G[m][2 * i + 1] = -2 * dy;
+            G[m][2 * j] = 2 * dx;  G[m][2 * j + 1] = 2 * dy;
+            h[m] = gain * hh * hh * hh;
+            ++m;
+        }
+    REAL q[ORC_MAXV], x[ORC_MAXV], s[ORC_MAXC], z[ORC_MAXC];
+    for (int a = 0; a < N; ++a) { /* "Threshold control inputs before QP" (in place, like rps) */
+        REAL nrm = SQRT(ux[a] * ux[a] + uy[a] * uy[a]);
+        if (nrm > p->barrier_magnitude_limit) {
+            ux[a] *= p->barrier_magnitude_limit / nrm;
+            uy[a] *= p->barrier_magnitude_limit / nrm;
+        }
+        q[2 * a] = -2 * ux[a];
+        q[2 * a + 1] = -2 * uy[a];
+    }
+    REAL nq = 0, nh = 0;
+    for (int k = 0; k < n; ++k) nq += q[k] * q[k];
+    for (int c = 0; c < m; ++c) nh += h[c] * h[c];
+    const REAL resx0 = SQRT(nq) > 1 ? SQRT(nq) : 1, resz0 = SQRT(nh) > 1 ? SQRT(nh) : 1;
+    REAL K[ORC_MAXV * ORC_MAXV], rhs[ORC_MAXV];
+    /* default starting point: [P G'; G -I][x; z] = [-q; h]  =>  (P + G'G) x = -q + G'h, z = G x - h, s = -z */
+    for (int a = 0; a < n; ++a) {
+        for (int b = 0; b < n; ++b) {
+            REAL v = a == b ? 2 : 0;
+            for (int c = 0; c < m; ++c) v += G[c][a] * G[c][b];
+            K[a * n + b] = v;
+        }
+        REAL v = -q[a];
+        for (int c = 0; c < m; ++c) v += G[c][a] * h[c];
+        rhs[a] = v;
+    }
+    if (FN(chol_solve)(n, K, rhs)) return -1;
+    for (int k = 0; k < n; ++k) x[k] = rhs[k];
+    REAL ns = 0, ts = -1e300, tz = -1e300;
+    for (int c = 0; c < m; ++c) {
+        REAL gx_ = 0;
+        for (int k = 0; k < n; ++k) gx_ += G[c][k] * x[k];
+        z[c] = gx_ - h[c];
+        s[c] = -z[c];
+        ns += s[c] * s[c];
+        if (-s[c] > ts) ts = -s[c];
+        if (-z[c] > tz) tz = -z[c];
+    }
+    ns = SQRT(ns);   /* (= ||z|| as well) */
+    if (ts >= -1e-8 * (ns > 1 ? ns : 1)) for (int c = 0; c < m; ++c) s[c] += 1 + ts;
+    if (tz >= -1e-8 * (ns > 1 ? ns : 1)) for (int c = 0; c < m; ++c) z[c] += 1 + tz;
+    REAL gap = 0;
+    for (int c = 0; c < m; ++c) gap += s[c] * z[c];
+    int iters;
+    for (iters = 0;; ++iters) {
+        REAL rx[ORC_MAXV], rz[ORC_MAXC], f0 = 0, resx = 0, resz = 0, zrz = 0;
+        for (int k = 0; k < n; ++k) {
+            REAL v = q[k] + 2 * x[k];          /* q + P x */
+            f0 += 0.5 * (x[k] * v + x[k] * q[k]);
+            for (int c = 0; c < m; ++c) v += G[c][k] * z[c];
+            rx[k] = v;
+            resx += v * v;
+        }
+        for (int c = 0; c < m; ++c) {
+            REAL v = s[c] - h[c];
+            for (int k = 0; k < n; ++k) v += G[c][k] * x[k];
+            rz[c] = v;
+            resz += v * v;
+            zrz += z[c] * v;
+        }
+        resx = SQRT(resx);
+        resz = SQRT(resz);
+        const REAL pcost = f0, dcost = f0 + zrz - gap;
+        const int have_rel = pcost < 0 || dcost > 0;
+        const REAL relgap = pcost < 0 ? gap / -pcost : dcost > 0 ? gap / dcost : 0;
+        const REAL pres = resz / resz0, dres = resx / resx0;
+        if ((pres <= FEASTOL && dres <= FEASTOL && (gap <= ABSTOL || (have_rel && relgap <= RELTOL))) || iters == MAXITERS) break;
+        /* Newton systems: (P + G' diag(z/s) G) dx = -rx - G'[(rc + z o rz) / s];  ds = -rz - G dx;  dz = (rc - z o ds) / s */
+        REAL Kf[ORC_MAXV * ORC_MAXV];
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) {
+                REAL v = a == b ? 2 : 0;
+                for (int c = 0; c < m; ++c) v += G[c][a] * (z[c] / s[c]) * G[c][b];
+                Kf[a * n + b] = v;
+            }
+        REAL dx[ORC_MAXV], ds[ORC_MAXC], dz[ORC_MAXC], dsa_dza[ORC_MAXC];
+        const REAL mu = gap / m;
+        REAL sigma = 0, step = 1;
+        int failed = 0;
+        for (int pass = 0; pass < 2 && !failed; ++pass) {
+            REAL rc[ORC_MAXC], Kc[ORC_MAXV * ORC_MAXV];
+            for (int c = 0; c < m; ++c) rc[c] = -s[c] * z[c] + sigma * mu - (pass ? dsa_dza[c] : 0);
+            for (int a = 0; a < n; ++a) {
+                REAL v = -rx[a];
+                for (int c = 0; c < m; ++c) v -= G[c][a] * ((rc[c] + z[c] * rz[c]) / s[c]);
+                dx[a] = v;
+            }
+            for (int k = 0; k < n * n; ++k) Kc[k] = Kf[k];
+            if (FN(chol_solve)(n, Kc, dx)) { failed = 1; break; }
+            REAL dsdz = 0, t = 0;
+            for (int c = 0; c < m; ++c) {
+                REAL gdx = 0;
+                for (int k = 0; k < n; ++k) gdx += G[c][k] * dx[k];
+                ds[c] = -rz[c] - gdx;
+                dz[c] = (rc[c] - z[c] * ds[c]) / s[c];
+                dsdz += ds[c] * dz[c];
+                if (-ds[c] / s[c] > t) t = -ds[c] / s[c];
+                if (-dz[c] / z[c] > t) t = -dz[c] / z[c];
+            }
+            if (pass == 0) {
+                step = t == 0 ? 1 : (1 / t < 1 ? 1 / t : 1);
+                REAL sg = 1 - step + dsdz / gap * step * step;
+                sg = sg < 0 ? 0 : sg > 1 ? 1 : sg;
+                sigma = sg * sg * sg;
+                for (int c = 0; c < m; ++c) dsa_dza[c] = ds[c] * dz[c];
+            } else {
+                step = t == 0 ? 1 : (STEP / t < 1 ? STEP / t : 1);
+            }
+        }
+        if (failed) break;
+        for (int k = 0; k < n; ++k) x[k] += step * dx[k];
+        gap = 0;
+        for (int c = 0; c < m; ++c) {
+            s[c] += step * ds[c];
+            z[c] += step * dz[c];
+            gap += s[c] * z[c];
+        }
+    }
+    for (int a = 0; a < N; ++a) {
+        ux[a] = x[2 * a];
+        uy[a] = x[2 * a + 1];
+    }
+    return iters;
+}
+#endif
+
 /* a3 = a4 . a5 . a6 . a7, then a8 (utilities/controller.py:20-24, roboEnv.py:64-65) */
 static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *cs, const REAL *ss,
                           const REAL *gx, const REAL *gy, REAL *v, REAL *w) {
@@ -290,7 +476,11 @@ static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL 
         ux[a] = dx;
         uy[a] = dy;
     }
+#if !ORC_IS_F32
+    int sweeps = p->qp_mode == 1 ? FN(barrier_qp_ipm)(p, N, xix, xiy, ux, uy) : FN(barrier_qp)(p, N, xix, xiy, ux, uy); /* a6 */
+#else
     int sweeps = FN(barrier_qp)(p, N, xix, xiy, ux, uy); /* a6 */
+#endif
     REAL inv_pd = R(1) / pd;
     REAL wlim = R(p->angular_velocity_limit);
     REAL vmax = R(p->max_linear_velocity);
