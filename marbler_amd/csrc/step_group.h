@@ -32,6 +32,24 @@
 
 namespace rg {
 
+// Output stores (observation rows, rewards, distances): -DRG_NT_STORES issues them as non-temporal (streaming) stores --
+// an experiment on the end-of-launch write-back; the shipped build uses plain stores.
+typedef float rg_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void out_store4(float *p, float a, float b, float c, float d) {
+#ifdef RG_NT_STORES
+    __builtin_nontemporal_store(rg_f4v{a, b, c, d}, reinterpret_cast<rg_f4v *>(p));
+#else
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+#endif
+}
+__device__ __forceinline__ void out_store1(float *p, float a) {
+#ifdef RG_NT_STORES
+    __builtin_nontemporal_store(a, p);
+#else
+    *p = a;
+#endif
+}
+
 #ifndef RG_CHUNK
 #define RG_CHUNK 5
 #endif
@@ -262,7 +280,7 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
         if (ok[r] & (all_others | (slot < Knb))) {
             float *o = obs_row + (slot + 1) * OD;
             if constexpr (OD == 4) {
-                *reinterpret_cast<float4 *>(o) = make_float4(row[r][0], row[r][1], row[r][2], row[r][3]);
+                out_store4(o, row[r][0], row[r][1], row[r][2], row[r][3]);
             } else {
 #pragma unroll
                 for (int c = 0; c < OD; ++c) o[c] = row[r][c];
@@ -939,7 +957,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             }
             write_neighbour_obs<GW, 6, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         } else {
-            if (lane_ok) *reinterpret_cast<float4 *>(obs_row) = make_float4(x, y, qx, qy);
+            if (lane_ok) out_store4(obs_row, x, y, qx, qy);
             write_neighbour_obs<GW, 4, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
         }
         RG_STAMP_E(1);  // observations written
@@ -1211,8 +1229,8 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             X[N + ag] = y;
             X[2 * N + ag] = th;
             a.st.carry_dist[eN + ag] = carry;
-            sv.io.reward[eN + ag] = reward;
-            sv.io.dist_travelled[eN + ag] = dist;
+            out_store1(sv.io.reward + eN + ag, reward);
+            out_store1(sv.io.dist_travelled + eN + ag, dist);
             if (ag == 0) {
                 a.st.episode_steps[e] = steps;
                 if (stats) {  // misc.py:178-185: episodeReward += reward[0] | sum(reward)

@@ -132,6 +132,12 @@ if __name__ == "__main__":
             torch.cuda.synchronize()
             print(json.dumps({"scenario": scn, "E": E, "api": "rg_rollout K=64", "us_per_step": a.elapsed_time(b) * 1e3 / (8 * 64),
                               "lib": os.environ.get("ROBOGYM_LIB", "shipped")}), flush=True)
+    if args.set == "headline":   # the headline launch and its neighbours, for A/B runs of library builds (ROBOGYM_LIB)
+        os.environ["RG_STEP_KERNEL"] = "group"
+        for scn, E in (("PredatorCapturePrey", 4096), ("PredatorCapturePrey", 4096), ("PredatorCapturePrey", 2048), ("PredatorCapturePrey", 32768)):
+            r = probe(scn, E, steps=1000, warm=200)
+            r["lib"] = os.environ.get("ROBOGYM_LIB", "shipped")
+            print(json.dumps(r), flush=True)
     if args.set == "big":     # one saturated configuration (for rocprofv3 --pmc runs); RG_STEP_KERNEL picks the kernel
         out.append(probe("PredatorCapturePrey", 524288, steps=20, warm=10))
     for r in out:
