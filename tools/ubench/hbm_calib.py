@@ -50,8 +50,7 @@ def run():
             n = lib.calib_run(mode, buf.data_ptr(), BYTES, epw, sink.data_ptr(), stream)
             torch.cuda.synchronize()
         print(json.dumps({"kernel": name, "envs_per_wave": epw, "bytes_per_launch": int(n)}), flush=True)
-    if 0 <= mode:   # the writes must not have run past the buffer's last pose block: spot check
-        assert float(sink.sum()) == 0.0
+    assert float(sink.sum()) == 0.0   # the read kernels' "never true" sink stayed untouched
 
 
 def summarize(tag, dbs, outdir=None):
