@@ -142,3 +142,28 @@ def test_baseline_shape_bit_exact_vs_oracle(name, scenario, ov, n_act, E, steps,
         assert torch.equal(sa[key], sb[key]), f"{name}: rg_rollout state {key}"
     env.close()
     twin.close()
+
+
+@pytest.mark.parametrize("scenario,ov,threshold", [
+    ("PredatorCapturePrey", PCP5, 65536),
+    ("PredatorCapturePrey", {"predator": 2, "capture": 1, "n_agents": 3}, 98304),
+    ("PredatorCapturePrey", {}, 196608),                                                   # the reference's default: 4 agents
+    ("Simple", {}, 393216),
+    ("MaterialTransport", MT6, 98304),
+    ("MaterialTransport", {"n_agents": 5, "n_fast_agents": 3, "n_slow_agents": 2, "start_dist": 0.25}, 49152),
+    ("Warehouse", {}, 131072),                                                             # default: 6 agents
+    ("Warehouse", WH8, None),                                                              # N >= 7: never
+])
+def test_kernel_choice_follows_the_measured_cross_overs(scenario, ov, threshold, monkeypatch):
+    """`rg_create` picks the step kernel from (scenario, agent count, batch size): the table of robogym_capi.hip
+    `tpe_min_envs`, measured with tools/crossover_probe.py (profiles/r3_crossover_probe.txt).  `rg_step_kernel` reports it."""
+    from marbler_amd import VecRobotariumEnv
+    monkeypatch.delenv("RG_STEP_KERNEL", raising=False)
+    for E, want in ((4096, "group"),) + (((threshold - 1, "group"), (threshold, "tpe")) if threshold else ((524288, "group"),)):
+        env = VecRobotariumEnv(scenario, E, overrides=ov, seed=0)
+        assert env.step_kernel == want, (scenario, E, env.step_kernel)
+        env.close()
+    monkeypatch.setenv("RG_STEP_KERNEL", "tpe")
+    env = VecRobotariumEnv(scenario, 64, overrides=ov, seed=0)
+    assert env.step_kernel == "tpe"          # every N <= 8 has a thread-per-env instantiation
+    env.close()
