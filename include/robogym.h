@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 3
+/* 4 (round 3): + rg_step_kernel(); rg_bind_state now invalidates the drawn-ahead blocks itself.  Structs unchanged since 3. */
+#define RG_ABI_VERSION 4
 #define RG_MAX_AGENTS 16
 #define RG_MAX_PREY 64
 

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 MAX_AGENTS, MAX_PREY = 16, 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 RESET_BOOK_EPISODE = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
