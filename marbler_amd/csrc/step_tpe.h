@@ -343,7 +343,11 @@ __device__ __forceinline__ void stage_obs_rows(const Stage &sg, float *obs, int 
     static_assert(RP >= 1, "one observation row of the whole wave must fit the staging block");
     // D > DMAX: a parameter block that asks for more neighbour slots than there are other agents (rows wider than the
     // agents fill, misc.py:20-25 / PredatorCapturePrey.py:198-201) -- the batch would overrun the staging block
+#ifdef RG_TPE_NO_DMAX_GUARD  // (test of the tests only: the round-2 condition, to show that the configuration fuzzer sees the overrun)
+    if ((D & 3) != 0) {
+#else
     if ((D & 3) != 0 || D > DMAX) {
+#endif
         float *mine = obs + sg.e * N * D;
         sfor<0, N>([&](auto AA) { fn(AA, mine + decltype(AA)::value * D); });
         return;

@@ -1,0 +1,64 @@
+"""Randomised configurations: scenario x agent count x neighbour slots x prey count x certificate x collision test x
+penalties x controller cadence x batch size x step kernel, drawn from a seeded generator inside the ranges the parameter
+block admits, each stepped free-running with auto-reset against the float32 oracle, bit for bit (the machinery of
+tests/test_gpu_rollout.py).  The hand-picked cases cover the reference's configurations; this covers the combinations nobody
+picked -- round 3 found by code review that rows wider than the agents fill overran the thread-per-env kernel's staging
+block, a shape no listed case had."""
+import numpy as np
+import pytest
+
+from test_gpu_rollout import _rollout_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def draw_config(rng):
+    scenario = str(rng.choice(["PredatorCapturePrey", "Warehouse", "MaterialTransport", "Simple", "ArcticTransport"],
+                              p=[0.35, 0.2, 0.2, 0.15, 0.1]))
+    ov, n_act = {}, 5
+    common = {"penalize_violations": bool(rng.rand() < 0.8), "barrier_certificate": str(rng.choice(["safe", "default"], p=[0.7, 0.3])),
+              "collision_variant": str(rng.choice(["offset", "center"], p=[0.7, 0.3])), "robotarium": bool(rng.rand() < 0.15)}
+    if scenario == "PredatorCapturePrey":
+        n = int(rng.randint(2, 17))
+        npred = int(rng.randint(1, n))
+        ov = {"predator": npred, "capture": n - npred, "n_agents": n, "num_prey": int(rng.choice([1, 2, 6, 8, 9, 12, 20, 33, 35])),
+              "num_neighbors": int(rng.randint(0, n + 3)), "capability_aware": bool(rng.rand() < 0.4),
+              "start_dist": 0.3 if n <= 16 else 0.25, "predator_radius": float(rng.choice([0.45, 0.3, 0.7])),
+              "capture_radius": float(rng.choice([0.25, 0.15, 0.4]))}
+        if ov["num_prey"] > 30:
+            ov["step_dist"] = 0.16                      # prey grid 5 x 11 = 55 cells
+    elif scenario == "Warehouse":
+        n = int(rng.randint(2, 17))
+        ov = {"n_agents": n, "num_neighbors": int(rng.randint(0, n + 3)), "start_dist": 0.6 if n < 12 else 0.4,
+              "goal_width": float(rng.choice([0.5, 0.3, 0.9]))}
+    elif scenario == "MaterialTransport":
+        n = int(rng.randint(4, 17))
+        nf = int(rng.randint(0, n + 1))
+        ov = {"n_agents": n, "n_fast_agents": nf, "n_slow_agents": n - nf, "start_dist": 0.3 if n <= 5 else 0.25 if n <= 13 else 0.2,
+              "capability_aware": bool(rng.rand() < 0.4)}
+        n_act = 20
+    elif scenario == "Simple":
+        ov = {"n_agents": int(rng.randint(2, 17))}
+    if scenario != "ArcticTransport":
+        ov.update(common)
+    else:
+        ov.update({k: common[k] for k in ("penalize_violations", "collision_variant")})
+    if ov.get("robotarium"):
+        ov["update_frequency"] = int(rng.choice([10, 17]))          # a controller every sub-step: keep the oracle affordable
+    E = int(rng.choice([1, 5, 63, 64, 65, 129, 300]))
+    kernel = str(rng.choice(["group", "tpe"]))
+    return scenario, ov, n_act, E, kernel
+
+
+CASES = [draw_config(np.random.RandomState(1000 + i)) for i in range(320)]
+
+
+@pytest.mark.parametrize("i", range(len(CASES)))
+def test_random_configuration_is_bit_exact(i, oracle_lib, monkeypatch):
+    scenario, ov, n_act, E, kernel = CASES[i]
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)       # (configurations the thread-per-env kernel does not cover run the lane-group one)
+    steps = 40 if scenario != "MaterialTransport" else 25
+    try:
+        _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E, require_done=False)
+    except AssertionError as exc:
+        raise AssertionError(f"case {i}: {scenario} {ov} E={E} kernel={kernel}: {exc}") from exc

@@ -60,7 +60,7 @@ def test_rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib):
     _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, 192)
 
 
-def _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E):
+def _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E, require_done=True):
     import torch
     from marbler_amd import VecRobotariumEnv
     seed = 99
@@ -109,7 +109,7 @@ def _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E):
         # state after the (possibly reset) step
         assert np.array_equal(env.poses.cpu().numpy().view(np.uint32), orc.poses.view(np.uint32)), t
         assert np.array_equal(env.episode_steps.cpu().numpy(), orc.steps), t
-    assert n_done > 0 or E < 8
+    assert n_done > 0 or E < 8 or not require_done
     assert np.array_equal(env.done_count.cpu().numpy(), episodes)
     assert np.array_equal(env.done_return_sum.cpu().numpy().view(np.uint32), ret_sum.view(np.uint32))
     assert np.array_equal(env.ep_return.cpu().numpy().view(np.uint32), ret.view(np.uint32))
