@@ -7,7 +7,7 @@ block, a shape no listed case had."""
 import numpy as np
 import pytest
 
-from test_gpu_rollout import _rollout_bit_exact
+from test_gpu_rollout import _rollout_bit_exact, _rollout_equals_steps
 
 pytestmark = pytest.mark.gpu
 
@@ -62,3 +62,16 @@ def test_random_configuration_is_bit_exact(i, oracle_lib, monkeypatch):
         _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E, require_done=False)
     except AssertionError as exc:
         raise AssertionError(f"case {i}: {scenario} {ov} E={E} kernel={kernel}: {exc}") from exc
+
+
+@pytest.mark.parametrize("i", range(0, len(CASES), 4))
+def test_random_configuration_multi_step_launch_equals_single_steps(i, monkeypatch):
+    """The same draws through rg_rollout (K steps per launch) against K rg_step launches (GPU against GPU, every output and
+    the final state), for the draws whose [E][N][D] block keeps rg_rollout's 16-byte alignment."""
+    from marbler_amd.params import load_config, make_params
+    scenario, ov, n_act, E, kernel = CASES[i]
+    p = make_params(scenario, load_config(scenario, None, ov))
+    if (E * p.n_agents * p.obs_dim) % 4:
+        pytest.skip("E*N*D is not a multiple of 4: rg_rollout rejects the shape (documented)")
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
+    _rollout_equals_steps(scenario, ov, n_act, E, K=12, reps=3, require_done=False)

@@ -228,16 +228,19 @@ def test_large_batch_dispatch_matches_lane_group_kernel(scenario, ov, n_act, E, 
 def test_rollout_entry_equals_repeated_steps(scenario, ov, n_act, E):
     """rg_rollout (K steps in one launch, envs advancing independently) against K rg_step launches:
     every per-step output and the final state, bit for bit, across auto-resets."""
+    _rollout_equals_steps(scenario, ov, n_act, E)
+
+
+def _rollout_equals_steps(scenario, ov, n_act, E, K=48, reps=3, require_done=True, time_limit=None):
     import torch
     from marbler_amd import VecRobotariumEnv
-    K = 48
     a = VecRobotariumEnv(scenario, E, overrides=ov, seed=21)
     b = VecRobotariumEnv(scenario, E, overrides=ov, seed=21)
     g = torch.Generator(device=a.device)
     g.manual_seed(4)
     a.reset()
     b.reset()
-    for rep in range(3):   # three launches of K steps: the state carries over between launches
+    for rep in range(reps):   # several launches of K steps: the state carries over between launches
         acts = torch.randint(0, n_act, (K, E, a.N), generator=g, device=a.device, dtype=torch.int32)
         out = a.rollout(acts)
         for k in range(K):
@@ -250,5 +253,7 @@ def test_rollout_entry_equals_repeated_steps(scenario, ov, n_act, E):
     sa, sb = a.state_dict(), b.state_dict()
     for key in sa:
         assert torch.equal(sa[key], sb[key]), key
-    assert torch.equal(a.done_count, b.done_count) and int(a.done_count.sum()) > 0
+    assert torch.equal(a.done_count, b.done_count) and (int(a.done_count.sum()) > 0 or not require_done)
     assert torch.equal(a.done_return_sum.view(torch.int32), b.done_return_sum.view(torch.int32))
+    a.close()
+    b.close()
