@@ -7,11 +7,13 @@ What this measures, and what it found (round 3; numbers in DESIGN.md section 2):
     boundary crossed one sub-step earlier, a prey sensed at the radius, a neighbour order at a tie): such steps are COUNTED and
     must be rare;
   * on every other step x, y and dist_travelled agree within north_star's 1e-5 for >= 99.9 % of the env steps of every
-    scenario -- but NOT for all of them: a unicycle reversing towards a goal behind it amplifies the 6e-8 rounding of the
-    float32 STATE itself by ~2.5x per controller period, and a pair inside the safety radius (the 1e6 gain) is stiff; over
-    MaterialTransport's five periods per step about 1.5e-4 of the steps end 1e-5 .. 6e-5 apart (29-sub-step scenarios: < 2e-5 of
-    the steps, up to 2.5e-5).  That is a property of float32 state, which north_star prescribes, not of the kernels'
-    arithmetic; the bound asserted here is the measured one with margin, and it is stated wherever the 1e-5 claim is made.
+    scenario -- but NOT for all of them: a unicycle reversing towards a goal behind it amplifies a heading error ~2.5x per
+    controller period, and a pair inside the safety radius (the 1e6 gain) is stiff; over MaterialTransport's five periods per
+    step about 1.5e-4 of the steps end 1e-5 .. 1e-4 apart (29-sub-step scenarios: < 2e-5 of the steps, up to 2.6e-5).  Such a
+    step amplifies ANY 1e-7 perturbation a thousandfold: the rounding of the float32 state it starts from (float64 arithmetic
+    from the rounded state is itself up to 3.9e-5 off) as much as the roundings of the float32 arithmetic inside it (up to
+    5.9e-5 from identical input).  The bound asserted here is the measured one with margin, and it is stated wherever the
+    1e-5 claim is made.
 """
 import numpy as np
 import pytest
