@@ -57,16 +57,21 @@ def expected_slots(N, E):
 
 @pytest.mark.parametrize("name,scenario,ov,n_act,E,steps,kernel,slots", CASES, ids=[c[0] for c in CASES])
 def test_baseline_shape_bit_exact_vs_oracle(name, scenario, ov, n_act, E, steps, kernel, slots, oracle_lib, monkeypatch):
-    import torch
-    from marbler_amd import VecRobotariumEnv
     if kernel is None:
         monkeypatch.delenv("RG_STEP_KERNEL", raising=False)
     else:
         monkeypatch.setenv("RG_STEP_KERNEL", kernel)
+    shape_rollout_vs_oracle(name, scenario, ov, n_act, E, steps, slots, oracle_lib)
+
+
+def shape_rollout_vs_oracle(name, scenario, ov, n_act, E, steps, slots, oracle_lib, check_rollout=True, seed=1234, action_seed=17):
+    """(RG_STEP_KERNEL is the caller's business.)  check_rollout=False: rg_step against the oracle only, no [K, ...] arrays
+    (tests/soak_shapes.py runs thousands of steps this way)."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
     threads = max(1, min(16, (os.cpu_count() or 1)))
-    seed = 1234
     env = VecRobotariumEnv(scenario, E, overrides=ov, seed=seed, auto_reset=True, collect_qp_stats=True)
-    twin = VecRobotariumEnv(scenario, E, overrides=ov, seed=seed, auto_reset=True, collect_qp_stats=True)  # rg_rollout
+    twin = VecRobotariumEnv(scenario, E, overrides=ov, seed=seed, auto_reset=True, collect_qp_stats=True) if check_rollout else None  # rg_rollout
     N = env.N
     if slots is not None:
         assert expected_slots(N, E) == slots, "the case no longer exercises the dispatch width it is named for"
@@ -74,23 +79,26 @@ def test_baseline_shape_bit_exact_vs_oracle(name, scenario, ov, n_act, E, steps,
     orc = oracle_lib.OracleVecEnv(scenario, cfg, E, dtype=np.float32)
     rp = oracle_reset_params(oracle_lib, env.params)
     env.reset()
-    twin.reset()
+    if twin is not None:
+        twin.reset()
     for e in range(E):
         oracle_reset(oracle_lib, orc, rp, seed, e, 0)
     assert np.array_equal(env.poses.cpu().numpy().view(np.uint32), orc.poses.view(np.uint32))
     episodes = np.zeros(E, np.int64)
-    rng = np.random.RandomState(17)
-    acts = rng.randint(0, n_act, size=(steps, E, N)).astype(np.int32)
-    acts_dev = torch.as_tensor(acts, device=env.device)
+    rng = np.random.RandomState(action_seed)
+    acts = rng.randint(0, n_act, size=(steps, E, N)).astype(np.int32) if check_rollout else None
+    acts_dev = torch.as_tensor(acts, device=env.device) if check_rollout else None
     kept = {k: [] for k in ("obs", "reward", "done", "dist_travelled", "violation", "remaining", "qp_sweeps")}
     n_done = n_viol = 0
     for t in range(steps):
-        obs, rew, done, info = env.step(acts_dev[t])
-        o_obs, o_rew, o_done, o_info = orc.step(acts[t], threads=threads)
+        act_t = acts[t] if check_rollout else rng.randint(0, n_act, size=(E, N)).astype(np.int32)
+        obs, rew, done, info = env.step(acts_dev[t] if check_rollout else torch.as_tensor(act_t, device=env.device))
+        o_obs, o_rew, o_done, o_info = orc.step(act_t, threads=threads)
         got = {"obs": obs, "reward": rew, "done": env.done_u8, "dist_travelled": info["dist_travelled"],
                "violation": info["violation"], "remaining": info["remaining"], "qp_sweeps": env.qp_sweeps}
-        for k_, v in got.items():
-            kept[k_].append(v.clone())
+        if check_rollout:
+            for k_, v in got.items():
+                kept[k_].append(v.clone())
         host = {k_: v.cpu().numpy() for k_, v in got.items()}
 
         def same(a, b, what):
@@ -132,6 +140,9 @@ def test_baseline_shape_bit_exact_vs_oracle(name, scenario, ov, n_act, E, steps,
     assert n_done > 0 and n_viol > 0, "the rollout must contain episode ends and violations"
     assert np.array_equal(env.done_count.cpu().numpy(), episodes)
     assert np.array_equal(env.reset_count.cpu().numpy(), episodes + 1)   # the explicit reset() drew episode 0
+    if not check_rollout:
+        env.close()
+        return {"env_steps": steps * E, "episodes": int(episodes.sum()), "violations": n_viol}
     # ---- the same action sequence through rg_rollout (one launch for all steps): what the oracle just confirmed, step by step
     out = twin.rollout(acts_dev)
     for k_ in kept:
