@@ -573,7 +573,11 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         // roundings of the 29..74 Euler updates do not pile up in x, y (float spec, oracle/oracle_core.h)
         float bx = x, by = y, ox = 0.0f, oy = 0.0f;
         const bool penalize = p.penalize_violations != 0;
+#ifdef RG_FIXED_U  // probe build only (tools/perf_probe.py --set headline): the sub-step counts as compile-time constants (29 / 15:
+        const int U = RG_FIXED_U, period = 15;  // PredatorCapturePrey, Warehouse, Simple) -- what the loop bookkeeping is worth
+#else
         const int U = p.update_frequency, period = p.controller_period;
+#endif
         for (int it0 = 0; it0 < U; it0 += period) {
             const int n = (U - it0) < period ? (U - it0) : period;
 #ifdef RG_STAMPS_CTRL
