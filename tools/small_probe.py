@@ -1,4 +1,4 @@
-import os, sys, json
+import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from marbler_amd import VecRobotariumEnv

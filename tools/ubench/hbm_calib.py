@@ -12,7 +12,6 @@ import argparse
 import ctypes
 import json
 import os
-import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MODES = [(0, "calib_read4", 0), (1, "calib_read16", 0), (2, "calib_write4", 0), (3, "calib_write16", 0), (6, "calib_write1", 0),
