@@ -50,6 +50,23 @@ def draw_config(rng):
     return scenario, ov, n_act, E, kernel
 
 
+def draw_config_extended(rng):
+    """draw_config plus the axes the first 320 draws hold fixed: sub-steps per env step (incl. a remainder chunk of every
+    length and steps shorter than a controller period), episode length (resets every few steps), step length, safety
+    radius, QP sweep cap and larger ragged batches.  Used by tests/fuzz_soak.py (a one-off campaign, not part of the tier)."""
+    scenario, ov, n_act, E, kernel = draw_config(rng)
+    if not ov.get("robotarium"):
+        ov["update_frequency"] = int(rng.choice([1, 4, 5, 11, 14, 15, 16, 29, 30, 33, 44, 61, 74]))
+    ov["max_episode_steps"] = int(rng.choice([1, 2, 3, 7, 20, 80]))
+    if rng.rand() < 0.3:
+        ov["qp_max_sweeps"] = int(rng.choice([1, 2, 3, 5, 9]))
+    if scenario in ("PredatorCapturePrey", "Warehouse", "Simple") and rng.rand() < 0.5:
+        ov["step_dist"] = float(rng.choice([0.16, 0.25, 0.3])) if ov.get("num_prey", 0) <= 30 else 0.16
+    if rng.rand() < 0.25:
+        E = int(rng.choice([257, 1000, 2049]))
+    return scenario, ov, n_act, E, kernel
+
+
 CASES = [draw_config(np.random.RandomState(1000 + i)) for i in range(320)]
 
 

@@ -280,3 +280,26 @@ def test_bench_launcher_timeout_is_below_the_drivers():
 def test_bench_refuses_a_rank_count_it_was_not_started_with():
     r = _run_bench("--gpus", "8", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_fuzzed_configurations_are_accepted_or_rejected_with_a_reason():
+    """The extended fuzz generator (tests/test_gpu_config_fuzz.py, tests/fuzz_soak.py) against the host's validation: every draw
+    either yields a parameter block inside the device's limits or raises ValueError naming what does not fit -- never a
+    block the kernels would index out of range with."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_config_fuzz import draw_config_extended
+    from marbler_amd.params import load_config, make_params
+    from marbler_amd._lib import MAX_AGENTS, MAX_PREY
+    accepted = 0
+    for i in range(200000, 200600):
+        scenario, ov, n_act, E, kernel = draw_config_extended(np.random.RandomState(i))
+        try:
+            p = make_params(scenario, load_config(scenario, None, ov))
+        except ValueError as exc:
+            assert len(str(exc)) > 10
+            continue
+        accepted += 1
+        assert 1 <= p.n_agents <= MAX_AGENTS and 0 <= p.num_prey <= MAX_PREY and p.obs_dim >= 1
+        assert p.update_frequency >= 1 and p.controller_period in (1, 15) and p.max_episode_steps >= 1 and p.qp_max_sweeps >= 1
+    assert accepted > 500
