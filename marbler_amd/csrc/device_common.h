@@ -132,6 +132,16 @@ __device__ __forceinline__ float group_max(float v) {
     if constexpr (GW >= 16) v = fmaxf(v, xor_lane<15>(v));
     return v;
 }
+// sum over the lanes of a group, the same butterfly: ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)) ... -- every lane ends
+// with the same bits (each stage adds the same two partial sums on both sides; binary32 addition commutes)
+template <int GW>
+__device__ __forceinline__ float group_sum(float v) {
+    v = v + xor_lane<1>(v);
+    v = v + xor_lane<2>(v);
+    if constexpr (GW >= 8) v = v + xor_lane<7>(v);
+    if constexpr (GW >= 16) v = v + xor_lane<15>(v);
+    return v;
+}
 // the same for NON-NEGATIVE floats, on their bit patterns (order-preserving; lets the DPP permute
 // fuse into v_max_u32 and needs no NaN canonicalisation)
 template <int GW>

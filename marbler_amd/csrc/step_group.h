@@ -89,7 +89,7 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         uy = clip ? uy * sc : uy;
     }
     // a6 barrier certificate: rows e_ij.(u_j - u_i) <= beta_ij, one per round; the exact projection
-    // by Hildreth sweeps with Aitken restarts (algorithm and derivation: oracle/oracle_core.h
+    // by Hildreth sweeps with vector-extrapolation restarts (algorithm and derivation: oracle/oracle_core.h
     // barrier_qp).  Per round: f = e/n2, bp = beta/n2, emax = max(|ex|, |ey|); absent pairs have
     // f = bp = emax = 0 and mu = 0, which makes every update of theirs an exact no-op.
     const float bgain = p.barrier_gain, ugain = p.unsafe_barrier_gain, qp_rtol = p.qp_rtol;
@@ -137,7 +137,7 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     bool active = upd;
     int sweeps = 0, my_sweeps = 0;
     // one sweep over the GW-1 rounds + the convergence test; PHASE = sweep number mod 4 selects the
-    // Aitken bookkeeping (record mu after sweeps 1 and 2 of each block of four, restart after the 3rd)
+    // restart bookkeeping (record mu after sweeps 1 and 2 of each block of four, restart after the 3rd)
     auto sweep = [&](auto PH) {
         constexpr int PHASE = decltype(PH)::value;
         ++sweeps;
@@ -164,18 +164,27 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
             const float gum = fmaxf(k.bml, group_max_nonneg<GW>(um));
             active = (gchg > qp_rtol * gum) & (sweeps < qp_cap);
             if constexpr (PHASE == 3) {
-                if (active) {  // Aitken restart of the multipliers, u rebuilt from them
-                    float sx = uhx, sy = uhy;
+                if (active) {  // restart: the multipliers extrapolated along their last change, u rebuilt from them
+                    float pa = 0.0f, pb = 0.0f, d2v[GW - 1];
                     static_for<1, GW>([&](auto KK) {
                         constexpr int K = decltype(KK)::value;
                         const float d1 = muB[K - 1] - muA[K - 1], d2 = mu[K - 1] - muB[K - 1];
-                        const bool geo = (d1 != 0.0f) & (d2 != 0.0f) & ((d1 > 0.0f) == (d2 > 0.0f)) &
-                                         (__builtin_fabsf(d2) < 0.97f * __builtin_fabsf(d1)) & (emax[K - 1] > 0.0f);
-                        float m = mu[K - 1] - (d2 * d2) / (d2 - d1);
+                        const float dd = d2 - d1;
+                        pa = __builtin_fmaf(dd, d2, pa);
+                        pb = __builtin_fmaf(dd, dd, pb);
+                        d2v[K - 1] = d2;
+                    });
+                    const float ga = group_sum<GW>(pa), gb = group_sum<GW>(pb);
+                    const bool ok = (gb > 0.0f) & (ga < 0.0f) & (-ga < 32.0f * gb);
+                    const float gam = ok ? ga / gb : 0.0f;  // the one division of a restart
+                    float sx = uhx, sy = uhy;
+                    static_for<1, GW>([&](auto KK) {
+                        constexpr int K = decltype(KK)::value;
+                        float m = __builtin_fmaf(-gam, d2v[K - 1], mu[K - 1]);
                         m = (m > 0.0f) ? m : 0.0f;
-                        mu[K - 1] = geo ? m : mu[K - 1];
-                        sx = __builtin_fmaf(mu[K - 1], ex[K - 1], sx);
-                        sy = __builtin_fmaf(mu[K - 1], ey[K - 1], sy);
+                        mu[K - 1] = m;
+                        sx = __builtin_fmaf(m, ex[K - 1], sx);
+                        sy = __builtin_fmaf(m, ey[K - 1], sy);
                     });
                     ux = sx;
                     uy = sy;

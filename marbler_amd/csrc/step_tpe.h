@@ -136,17 +136,48 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         for (int a = 0; a < N; ++a) umax = fmaxf(umax, fmaxf(__builtin_fabsf(ux[a]), __builtin_fabsf(uy[a])));
         active = (chg > qp_rtol * umax) & (sweeps < qp_cap);
         if constexpr (PHASE == 3) {
-            if (active) {  // Aitken restart of the multipliers; u rebuilt agent by agent in round order
+            if (active) {  // restart (oracle_core.h barrier_qp): one extrapolation factor for all multipliers; u rebuilt agent by agent
+                constexpr int GW = group_width<N>();
+                // <dd, d2> and <dd, dd> per agent over its partners in round order, then in the order of the lane-group kernel's
+                // butterfly ((s0 + s1) + (s2 + s3)) + ...; agents >= N would add exact zeros and are left out
+                float pa[GW], pb[GW];
+                sfor<0, GW>([&](auto AA) {
+                    constexpr int a = decltype(AA)::value;
+                    pa[a] = pb[a] = 0.0f;
+                    if constexpr (a < N) {
+                        sfor<1, GW>([&](auto KK) {
+                            constexpr int q = a ^ decltype(KK)::value;
+                            if constexpr (q < N) {
+                                constexpr int lo = a < q ? a : q, hi = a < q ? q : a;
+                                const float d1 = muB[lo][hi] - muA[lo][hi], d2 = mu[lo][hi] - muB[lo][hi];
+                                const float dd = d2 - d1;
+                                pa[a] = __builtin_fmaf(dd, d2, pa[a]);
+                                pb[a] = __builtin_fmaf(dd, dd, pb[a]);
+                            }
+                        });
+                    }
+                });
+                sfor<0, 4>([&](auto LL) {
+                    constexpr int stride = 1 << decltype(LL)::value;
+                    if constexpr (stride < GW) {
+                        sfor<0, GW / (2 * stride)>([&](auto BB) {
+                            constexpr int a = decltype(BB)::value * 2 * stride;
+                            if constexpr (a + stride < N) {  // a right-hand side made of absent agents only is an exact zero
+                                pa[a] = pa[a] + pa[a + stride];
+                                pb[a] = pb[a] + pb[a + stride];
+                            }
+                        });
+                    }
+                });
+                const float ga = pa[0], gb = pb[0];
+                const bool ok = (gb > 0.0f) & (ga < 0.0f) & (-ga < 32.0f * gb);
+                const float gam = ok ? ga / gb : 0.0f;
                 for_pairs<N>([&](auto II, auto JJ) {
                     constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
-                    const float d1 = muB[i][j] - muA[i][j], d2 = mu[i][j] - muB[i][j];
-                    const bool geo = (d1 != 0.0f) & (d2 != 0.0f) & ((d1 > 0.0f) == (d2 > 0.0f)) &
-                                     (__builtin_fabsf(d2) < 0.97f * __builtin_fabsf(d1)) & (emax[i][j] > 0.0f);
-                    float m = mu[i][j] - (d2 * d2) / (d2 - d1);
+                    float m = __builtin_fmaf(-gam, mu[i][j] - muB[i][j], mu[i][j]);
                     m = (m > 0.0f) ? m : 0.0f;
-                    mu[i][j] = geo ? m : mu[i][j];
+                    mu[i][j] = m;
                 });
-                constexpr int GW = group_width<N>();
                 sfor<0, N>([&](auto AA) {
                     constexpr int a = decltype(AA)::value;
                     float sx = uhx[a], sy = uhy[a];

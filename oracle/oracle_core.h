@@ -157,9 +157,15 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
      * pair-parallel.  One pair update, with f = e/n2, bp = beta/n2, n2 = 2|e|^2:
      *     mn = max(0, mu - bp + f.(u_j - u_i));  delta = mn - mu;  u_i += delta e;  u_j -= delta e.
      * Coupled constraints converge geometrically (ratio <= 1/4 per sweep for two pairs sharing a
-     * robot), so after sweeps 3, 7, 11, ... the multipliers are Aitken-extrapolated
-     * (mu - d2^2/(d2 - d1) where the last two changes d1, d2 shrink with a common sign) and u is
-     * rebuilt from them: a restart from a better point of the same convergent iteration. */
+     * robot, closer to 1 for clusters of three and more), so after sweeps 3, 7, 11, ... the whole
+     * multiplier vector is extrapolated along its last change: with d1, d2 the last two changes of mu and
+     * dd = d2 - d1, gamma = <dd, d2> / <dd, dd> (the least-squares fit of d2 ~ r d1, gamma = r / (r - 1)) and
+     * mu <- max(0, mu - gamma d2) -- Aitken's delta-squared for vectors (reduced-rank extrapolation of order one):
+     * ONE division per restart, accepted for 0 < r < 32/33 -- and u is rebuilt from the multipliers: a restart
+     * from a better point of the same convergent iteration.  (Rounds 1-3 extrapolated each multiplier by its
+     * own scalar Aitken step: one division per pair, 1.7 sweeps' worth of time per restart on the GPU, and a
+     * longer tail -- DESIGN.md section 4.4.)  The two inner products are summed per robot over its partners
+     * in round order and then over the robots in the order of the HIP kernel's lane butterfly. */
     int gw = 2;
     while (gw < N) gw *= 2;
     REAL r2 = R(p->safety_radius) * R(p->safety_radius);
@@ -241,17 +247,37 @@ static int FN(barrier_qp)(const orc_params *p, int N, const REAL *xix, const REA
             if (ay > umax) umax = ay;
         }
         if (!(maxchg > R(p->qp_rtol) * umax) || sweeps >= p->qp_max_sweeps) break;
-        if ((sweeps & 3) == 3) { /* Aitken restart */
+        if ((sweeps & 3) == 3) { /* restart: one extrapolation factor for the whole multiplier vector */
+            REAL pa[ORC_MAXN], pb[ORC_MAXN];
+            for (int a = 0; a < gw; ++a) { /* per robot, over its partners in round order (each pair counts twice) */
+                pa[a] = pb[a] = R(0);
+                if (a >= N) continue;
+                for (int k = 1; k < gw; ++k) {
+                    int q = a ^ k;
+                    if (q >= N) continue;
+                    int lo = a < q ? a : q, hi = a < q ? q : a;
+                    if (!valid[lo][hi]) continue;
+                    REAL d1 = muB[lo][hi] - muA[lo][hi], d2 = mu[lo][hi] - muB[lo][hi];
+                    REAL dd = d2 - d1;
+                    pa[a] = FMA(dd, d2, pa[a]);
+                    pb[a] = FMA(dd, dd, pb[a]);
+                }
+            }
+            for (int stride = 1; stride < gw; stride *= 2) /* the lane butterfly of the HIP kernel: (s0+s1)+(s2+s3) ... */
+                for (int a = 0; a < gw; a += 2 * stride) {
+                    pa[a] = pa[a] + pa[a + stride];
+                    pb[a] = pb[a] + pb[a + stride];
+                }
+            REAL ga = pa[0], gb = pb[0];
+            int ok = gb > R(0) && ga < R(0) && -ga < R(32) * gb;
+            REAL gam = ok ? ga / gb : R(0); /* the one division of a restart */
             for (int i = 0; i < N; ++i)
                 for (int j = i + 1; j < N; ++j) {
                     if (!valid[i][j]) continue;
-                    REAL d1 = muB[i][j] - muA[i][j], d2 = mu[i][j] - muB[i][j];
-                    REAL a1 = d1 < R(0) ? -d1 : d1, a2 = d2 < R(0) ? -d2 : d2;
-                    if (d1 != R(0) && d2 != R(0) && ((d1 > R(0)) == (d2 > R(0))) && a2 < R(0.97) * a1) {
-                        REAL m = mu[i][j] - (d2 * d2) / (d2 - d1);
-                        if (!(m > R(0))) m = R(0);
-                        mu[i][j] = m;
-                    }
+                    REAL d2 = mu[i][j] - muB[i][j];
+                    REAL m = FMA(-gam, d2, mu[i][j]);
+                    if (!(m > R(0))) m = R(0);
+                    mu[i][j] = m;
                 }
             for (int a = 0; a < N; ++a) { /* u = uhat + sum over partners, in round order */
                 REAL sx = uhx[a], sy = uhy[a];

@@ -42,8 +42,8 @@ def solve_pair_qp(uhat, x, beta, rtol=QP_RTOL_F64, max_sweeps=QP_MAX_SWEEPS_F64,
     e_ij = x_i - x_j.  (Upstream's row  -2e.u_i + 2e.u_j <= b  divided by two; beta = b/2.)
     beta is a dict {(i,j): value}.  Returns (u, sweeps).
 
-    Hildreth sweeps in the XOR-factorisation pair order, with an Aitken restart of the
-    multipliers after sweeps 3, 7, 11, ... (see oracle/oracle_core.h barrier_qp, the same
+    Hildreth sweeps in the XOR-factorisation pair order, with a vector (delta-squared) extrapolation
+    of the multipliers after sweeps 3, 7, 11, ... (see oracle/oracle_core.h barrier_qp, the same
     algorithm in C)."""
     N = uhat.shape[1]
     gw = group_width(N)
@@ -78,10 +78,27 @@ def solve_pair_qp(uhat, x, beta, rtol=QP_RTOL_F64, max_sweeps=QP_MAX_SWEEPS_F64,
         if maxchg <= rtol * umax or sweeps >= max_sweeps:
             break
         if (sweeps & 3) == 3:
+            pa, pb = [0.0] * gw, [0.0] * gw           # per robot over its partners in round order, then the lane butterfly
+            for a in range(N):
+                for k in range(1, gw):
+                    q = a ^ k
+                    pr = (min(a, q), max(a, q))
+                    if q >= N or pr not in mu:
+                        continue
+                    d1, d2 = muB[pr] - muA[pr], mu[pr] - muB[pr]
+                    dd = d2 - d1
+                    pa[a] += dd * d2
+                    pb[a] += dd * dd
+            stride = 1
+            while stride < gw:
+                for a in range(0, gw, 2 * stride):
+                    pa[a] += pa[a + stride]
+                    pb[a] += pb[a + stride]
+                stride *= 2
+            ga, gb = pa[0], pb[0]
+            gam = ga / gb if (gb > 0.0 and ga < 0.0 and -ga < 32.0 * gb) else 0.0
             for pr in order:
-                d1, d2 = muB[pr] - muA[pr], mu[pr] - muB[pr]
-                if d1 != 0.0 and d2 != 0.0 and ((d1 > 0) == (d2 > 0)) and abs(d2) < 0.97 * abs(d1):
-                    mu[pr] = max(0.0, mu[pr] - (d2 * d2) / (d2 - d1))
+                mu[pr] = max(0.0, mu[pr] - gam * (mu[pr] - muB[pr]))
             u = uhat.copy()
             for a in range(N):
                 for k in range(1, gw):
