@@ -547,7 +547,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_kind": "from_committed_profile (rocprofv3 --pmc passes of this command; not measured in this run): "
                                          "2 x FETCH_SIZE + WRITE_SIZE, the factors calibrated on known byte counts in the kernels' own "
-                                         "access shapes (profiles/r3_hbm_calibration.csv); an upper bound: 0.18 MB reported (0.18-0.36 MB of "
+                                         "access shapes (profiles/r3_hbm_calibration.csv); an upper bound: 0.17 MB reported (0.17-0.35 MB of "
                                          "bytes, factor uncalibrated for instruction fetches) is the kernel's own instructions, fetched by each "
                                          "of the 8 XCD L2s per launch (profiles/r3_fetch_floor_pmc_summary.csv)",
                          "traffic_source": counters_src, "valu": valu,

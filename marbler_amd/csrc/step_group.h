@@ -96,7 +96,7 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     const int qp_cap = p.qp_max_sweeps;
     const bool has_unsafe = p.barrier_has_unsafe_gain != 0;
     float ex[GW - 1], ey[GW - 1], fx[GW - 1], fy[GW - 1], bp[GW - 1], emax[GW - 1];
-    float mu[GW - 1], muA[GW - 1], muB[GW - 1];
+    float mu[GW - 1], dmu[GW - 1];  // dmu: the change of mu over sweep 2 (d1), then over sweep 3 (d2), of a block of four sweeps
     static_for<1, GW>([&](auto KK) {
         constexpr int K = decltype(KK)::value;
         const float pxi = xor_lane<K>(xix), pyi = xor_lane<K>(xiy);
@@ -114,11 +114,28 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         fy[K - 1] = dy * rn2;
         bp[K - 1] = (0.5f * b) * rn2;
         emax[K - 1] = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
-        mu[K - 1] = muA[K - 1] = muB[K - 1] = 0.0f;
+        mu[K - 1] = dmu[K - 1] = 0.0f;
     });
 #ifdef RG_STAMPS_CTRL
 #pragma unroll
     for (int r_ = 0; r_ < GW - 1; ++r_) asm volatile("" ::"v"(fx[r_]), "v"(bp[r_]), "v"(emax[r_]));
+#endif
+#ifdef RG_PROBE_SETUP_TWICE  // probe: what the pair constants cost (a shadow copy of the block above; results discarded)
+    static_for<1, GW>([&](auto KK) {
+        constexpr int K = decltype(KK)::value;
+        float pxi = xor_lane<K>(xiy), pyi = xor_lane<K>(xix);
+        asm volatile("" : "+v"(pxi), "+v"(pyi));
+        const float dx = xix - pxi, dy = xiy - pyi;
+        const float ee = dx * dx + dy * dy;
+        const float h = ee - k.r2;
+        const float gain = ((h >= 0.0f) | !has_unsafe) ? bgain : ugain;
+        const float b = gain * ((h * h) * h);
+        const float n2 = 2.0f * ee;
+        const bool ok = lane_ok & ((ag ^ K) < N) & (n2 > 0.0f);
+        const float rn2 = ok ? 1.0f / n2 : 0.0f;
+        float q0 = dx * rn2, q1 = dy * rn2, q2 = (0.5f * b) * rn2, q3 = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
+        asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));
+    });
 #endif
     RG_CTRL_TICK(0);  // position controller + pair constants
     {   // "Threshold control inputs before QP": decided on squares; never taken after the 0.15 clip
@@ -137,12 +154,15 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     bool active = upd;
     int sweeps = 0, my_sweeps = 0;
     // one sweep over the GW-1 rounds + the convergence test; PHASE = sweep number mod 4 selects the
-    // restart bookkeeping (record mu after sweeps 1 and 2 of each block of four, restart after the 3rd)
+    // restart bookkeeping: d1 and d2 of oracle_core.h (the changes of the multipliers over sweeps 2 and 3 of a block of four)
+    // are these sweeps' own deltas -- nothing touches mu between them -- so sweep 2 records its delta, sweep 3 forms the two
+    // inner products <d2 - d1, d2>, <d2 - d1, d2 - d1> while it runs (independent of its dependent chain: free issue slots)
+    // and leaves d2 in place of d1 for the restart
     auto sweep = [&](auto PH) {
         constexpr int PHASE = decltype(PH)::value;
         ++sweeps;
         if (active) {
-            float chg = 0.0f;
+            float chg = 0.0f, pa = 0.0f, pb = 0.0f;
             static_for<1, GW>([&](auto KK) {
                 constexpr int K = decltype(KK)::value;
                 const float pux = xor_lane<K>(ux), puy = xor_lane<K>(uy);
@@ -155,8 +175,13 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
                 ux = __builtin_fmaf(delta, ex[K - 1], ux);
                 uy = __builtin_fmaf(delta, ey[K - 1], uy);
                 chg = fmaxf(chg, __builtin_fabsf(delta) * emax[K - 1]);
-                if constexpr (PHASE == 1) muA[K - 1] = mn;
-                if constexpr (PHASE == 2) muB[K - 1] = mn;
+                if constexpr (PHASE == 2) dmu[K - 1] = delta;
+                if constexpr (PHASE == 3) {
+                    const float dd = delta - dmu[K - 1];
+                    pa = __builtin_fmaf(dd, delta, pa);
+                    pb = __builtin_fmaf(dd, dd, pb);
+                    dmu[K - 1] = delta;
+                }
             });
             my_sweeps = sweeps;
             const float um = lane_ok ? fmaxf(__builtin_fabsf(ux), __builtin_fabsf(uy)) : 0.0f;
@@ -165,22 +190,13 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
             active = (gchg > qp_rtol * gum) & (sweeps < qp_cap);
             if constexpr (PHASE == 3) {
                 if (active) {  // restart: the multipliers extrapolated along their last change, u rebuilt from them
-                    float pa = 0.0f, pb = 0.0f, d2v[GW - 1];
-                    static_for<1, GW>([&](auto KK) {
-                        constexpr int K = decltype(KK)::value;
-                        const float d1 = muB[K - 1] - muA[K - 1], d2 = mu[K - 1] - muB[K - 1];
-                        const float dd = d2 - d1;
-                        pa = __builtin_fmaf(dd, d2, pa);
-                        pb = __builtin_fmaf(dd, dd, pb);
-                        d2v[K - 1] = d2;
-                    });
                     const float ga = group_sum<GW>(pa), gb = group_sum<GW>(pb);
                     const bool ok = (gb > 0.0f) & (ga < 0.0f) & (-ga < 32.0f * gb);
                     const float gam = ok ? ga / gb : 0.0f;  // the one division of a restart
                     float sx = uhx, sy = uhy;
                     static_for<1, GW>([&](auto KK) {
                         constexpr int K = decltype(KK)::value;
-                        float m = __builtin_fmaf(-gam, d2v[K - 1], mu[K - 1]);
+                        float m = __builtin_fmaf(-gam, dmu[K - 1], mu[K - 1]);
                         m = (m > 0.0f) ? m : 0.0f;
                         mu[K - 1] = m;
                         sx = __builtin_fmaf(m, ex[K - 1], sx);

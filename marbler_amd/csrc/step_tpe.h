@@ -58,6 +58,21 @@ __device__ __forceinline__ void for_pairs(F &&f) {
     });
 }
 
+template <int LO, int W, int N>
+__device__ __forceinline__ void block_sums(const float (&pa)[N], const float (&pb)[N], float &sa, float &sb) {
+    if constexpr (W == 1) {
+        sa = pa[LO];
+        sb = pb[LO];
+    } else {
+        block_sums<LO, W / 2, N>(pa, pb, sa, sb);
+        if constexpr (LO + W / 2 < N) {
+            float ra, rb;
+            block_sums<LO + W / 2, W / 2, N>(pa, pb, ra, rb);
+            sa = sa + ra;
+            sb = sb + rb;
+        }
+    }
+}
 // ------------------------------------------------------------------ controller (a3..a8)
 template <int N>
 __device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, const float (&x)[N],
@@ -114,6 +129,9 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     auto sweep = [&](auto PH) {
         constexpr int PHASE = decltype(PH)::value;
         float chg = 0.0f;
+        float pa[N], pb[N];
+#pragma unroll
+        for (int a_ = 0; a_ < N; ++a_) pa[a_] = pb[a_] = 0.0f;
         for_pairs<N>([&](auto II, auto JJ) {
             constexpr int i = decltype(II)::value, j = decltype(JJ)::value;
             const float c0 = mu[i][j] - bp[i][j];
@@ -129,6 +147,14 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
             chg = fmaxf(chg, __builtin_fabsf(delta) * emax[i][j]);
             if constexpr (PHASE == 1) muA[i][j] = mn;
             if constexpr (PHASE == 2) muB[i][j] = mn;
+            if constexpr (PHASE == 3) {
+                const float d1 = muB[i][j] - muA[i][j], d2 = mn - muB[i][j];
+                const float dd = d2 - d1;
+                pa[i] = __builtin_fmaf(dd, d2, pa[i]);
+                pb[i] = __builtin_fmaf(dd, dd, pb[i]);
+                pa[j] = __builtin_fmaf(dd, d2, pa[j]);
+                pb[j] = __builtin_fmaf(dd, dd, pb[j]);
+            }
         });
         ++sweeps;
         float umax = k.bml;
@@ -140,36 +166,8 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
                 constexpr int GW = group_width<N>();
                 // <dd, d2> and <dd, dd> per agent over its partners in round order, then in the order of the lane-group kernel's
                 // butterfly ((s0 + s1) + (s2 + s3)) + ...; agents >= N would add exact zeros and are left out
-                float pa[GW], pb[GW];
-                sfor<0, GW>([&](auto AA) {
-                    constexpr int a = decltype(AA)::value;
-                    pa[a] = pb[a] = 0.0f;
-                    if constexpr (a < N) {
-                        sfor<1, GW>([&](auto KK) {
-                            constexpr int q = a ^ decltype(KK)::value;
-                            if constexpr (q < N) {
-                                constexpr int lo = a < q ? a : q, hi = a < q ? q : a;
-                                const float d1 = muB[lo][hi] - muA[lo][hi], d2 = mu[lo][hi] - muB[lo][hi];
-                                const float dd = d2 - d1;
-                                pa[a] = __builtin_fmaf(dd, d2, pa[a]);
-                                pb[a] = __builtin_fmaf(dd, dd, pb[a]);
-                            }
-                        });
-                    }
-                });
-                sfor<0, 4>([&](auto LL) {
-                    constexpr int stride = 1 << decltype(LL)::value;
-                    if constexpr (stride < GW) {
-                        sfor<0, GW / (2 * stride)>([&](auto BB) {
-                            constexpr int a = decltype(BB)::value * 2 * stride;
-                            if constexpr (a + stride < N) {  // a right-hand side made of absent agents only is an exact zero
-                                pa[a] = pa[a] + pa[a + stride];
-                                pb[a] = pb[a] + pb[a + stride];
-                            }
-                        });
-                    }
-                });
-                const float ga = pa[0], gb = pb[0];
+                float ga, gb;
+                block_sums<0, GW, N>(pa, pb, ga, gb);
                 const bool ok = (gb > 0.0f) & (ga < 0.0f) & (-ga < 32.0f * gb);
                 const float gam = ok ? ga / gb : 0.0f;
                 for_pairs<N>([&](auto II, auto JJ) {

@@ -162,7 +162,8 @@ def shape_rollout_vs_oracle(name, scenario, ov, n_act, E, steps, slots, oracle_l
     ("Simple", {}, 393216),
     ("MaterialTransport", MT6, 98304),
     ("MaterialTransport", {"n_agents": 5, "n_fast_agents": 3, "n_slow_agents": 2, "start_dist": 0.25}, 49152),
-    ("Warehouse", {}, 131072),                                                             # default: 6 agents
+    ("Warehouse", {}, None),                                                               # default: 6 agents: lane-group at every size
+    ("PredatorCapturePrey", {"predator": 3, "capture": 3, "n_agents": 6}, 262144),
     ("Warehouse", WH8, None),                                                              # N >= 7: never
 ])
 def test_kernel_choice_follows_the_measured_cross_overs(scenario, ov, threshold, monkeypatch):

@@ -48,9 +48,11 @@ def test_thread_per_env_kernel_keeps_two_waves_per_simd():
         assert r["LDS Size"] <= 20 * 1024, (name, r)   # eight one-wave workgroups per CU: the staging block must leave room
         assert r["Occupancy"] >= 2, (name, r)
         if "Li0ELi6ELb0E" in name:
-            # N = 6 (15 pairs) needs 256 + 40 registers and is compiled for two waves per SIMD all the same: ~40 values in
-            # scratch, measured +21..34 % at 524288 envs
-            assert r["ScratchSize"] <= 256, (name, r)
+            # N = 6 (15 pairs) needs 256 + 40 registers and is compiled for two waves per SIMD all the same: values in
+            # scratch, measured +21..34 % at 524288 envs against one wave per SIMD.  The byte count is a poor guide to the cost
+            # (round 3: 256 bytes with 196 scratch instructions ran 20 % slower than 304 bytes with 94: what matters is where
+            # they sit), so the instruction count is what tools/tpe_ab_probe.py times; this only catches a collapse.
+            assert r["ScratchSize"] <= 320, (name, r)
         else:   # N = 5, the benchmark instantiation: two waves per SIMD without a spill
             assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
 
