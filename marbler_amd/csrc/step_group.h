@@ -79,6 +79,17 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     unsigned long long ctrl_t = __builtin_amdgcn_s_memtime();
 #endif
     // a4 uni_to_si_states, a5 si_position_controller (gain 1, |dxi| <= 0.15)
+#ifdef RG_SHADOW_POS
+    {
+        float ax = gx - (x + k.pd * s), ay = gy - (y + k.pd * c);
+        const float nrm = norm2_spec(ax, ay);
+        const float sc = k.pvl / nrm;
+        const bool clip = nrm > k.pvl;
+        ax = clip ? ax * sc : ax;
+        ay = clip ? ay * sc : ay;
+        asm volatile("" ::"v"(ax), "v"(ay));
+    }
+#endif
     const float xix = x + k.pd * c, xiy = y + k.pd * s;
     float ux = gx - xix, uy = gy - xiy;
     {
@@ -188,6 +199,13 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
             const float gchg = group_max_nonneg<GW>(chg);
             const float gum = fmaxf(k.bml, group_max_nonneg<GW>(um));
             active = (gchg > qp_rtol * gum) & (sweeps < qp_cap);
+#ifdef RG_SHADOW_CONV  // probes (shadow copies, results discarded): what a block costs on the launch's critical path
+            {
+                float g2 = group_max_nonneg<GW>(chg * 1.5f), g3 = fmaxf(k.bml, group_max_nonneg<GW>(um * 1.5f));
+                bool a2 = (g2 > qp_rtol * g3) & (sweeps < qp_cap);
+                asm volatile("" ::"s"(__ballot(a2)));
+            }
+#endif
             if constexpr (PHASE == 3) {
                 if (active) {  // restart: the multipliers extrapolated along their last change, u rebuilt from them
                     const float ga = group_sum<GW>(pa), gb = group_sum<GW>(pb);
@@ -615,6 +633,13 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 #else
             sincos_spec(th, s, c);
             const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w);
+#ifdef RG_SHADOW_SINCOS
+            {
+                float s2, c2;
+                sincos_spec(th * 1.0001f, s2, c2);
+                asm volatile("" ::"v"(s2), "v"(c2));
+            }
+#endif
 #endif
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
             const float dtv = k.dt * v, dtw = k.dt * w;
@@ -706,6 +731,12 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     constexpr int SPAN0 = C - 1 < 2 ? C - 1 : 2;
                     const int t0 = SPAN0 == 0 ? thr_pre : SPAN0 == 1 ? thr_s1 : thr_s2;
                     dmin_u[0] = pair_min(q[0]);
+#ifdef RG_SHADOW_PAIRMIN
+                    {
+                        int d2_ = pair_min(q[C > 1 ? 1 : 0]);
+                        asm volatile("" ::"v"(d2_));
+                    }
+#endif
                     sparse_hit = sparse_hit | (dmin_u[0] <= t0);
                     if constexpr (C >= 4) {
                         const int t3 = C == 4 ? thr_pre : thr_s1;
@@ -988,6 +1019,10 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         } else {
             if (lane_ok) out_store4(obs_row, x, y, qx, qy);
             write_neighbour_obs<GW, 4, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
+#ifdef RG_SHADOW_KNN
+            asm volatile("" ::: "memory");
+            write_neighbour_obs<GW, 4, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
+#endif
         }
         RG_STAMP_E(1);  // observations written
         if constexpr (!OBS_ONLY) {  // a14 reward / termination (PredatorCapturePrey.py:155-176, 209-216)
