@@ -250,6 +250,43 @@ def rollout_leg(env, dev, n_act, seed, launches=16):
             "agent_steps_per_s": env.E * env.N / (ms * 1e-3), "hbm_achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
 
 
+def graph_leg(env, dev, ptrs, K, regions=40):
+    """The timed region's K rg_step launches recorded once into a hipGraph and replayed: the same kernels, no host call
+    per step.  A 20-step region launched step by step is exposed to the host's jitter (1 region in 8 ran 10-20 % slow on
+    the GPU box, tools/graph_region_probe.py); replayed as a graph its median is ~3 % lower and the tail goes away.
+    Reported beside the headline, which stays one host call per step (what a policy-in-the-loop trainer without a
+    captured loop makes).  Any failure here is reported as such and never touches the line's value."""
+    import torch
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        prev = env._stream
+        env.set_stream(side)
+        try:
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    for i in range(K):
+                        env.step_raw(ptrs[i % len(ptrs)])
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                t = []
+                for _ in range(regions):
+                    t0 = time.perf_counter()
+                    graph.replay()
+                    torch.cuda.synchronize(dev)
+                    t.append((time.perf_counter() - t0) / K)
+        finally:
+            env.set_stream(prev)
+            torch.cuda.current_stream(dev).wait_stream(side)
+        t.sort()
+        med = t[len(t) // 2]
+        return {"api": f"one hipGraph of {K} rg_step launches", "regions": regions, "ms_per_step_median": med * 1e3,
+                "ms_per_step_min": t[0] * 1e3, "ms_per_step_max": t[-1] * 1e3, "agent_steps_per_s_median": env.E * env.N / med}
+    except Exception as exc:   # noqa: BLE001 - a side measurement
+        return {"error": repr(exc)[:200]}
+
+
 def saturated_leg(dev, overrides, E=SATURATED_ENVS):
     """The same step at a batch that fills the chip (524288 envs = 8 waves per SIMD, and 2097152 = 32, where the
     ragged end of the launch weighs less; thread-per-env kernel): where the path stands against the HBM roof
@@ -570,6 +607,7 @@ def main():
                                "mean_return": float(rs.sum().item() / max(n_ep, 1)),
                                "mean_length": float(ss.sum().item() / max(n_ep, 1))}
         if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey":
+            out["graph_replay"] = graph_leg(env, dev, ptrs, min(K, 100))
             out["rollout"] = rollout_leg(env, dev, n_act, 777)
             out["saturated"] = saturated_leg(dev, overrides)
             out["saturated_2m"] = saturated_leg(dev, overrides, 4 * SATURATED_ENVS)
