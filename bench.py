@@ -433,6 +433,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 524288-env side measurement")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="skip the graph_replay side measurement (profiling runs: its launches would mix into the headline kernel's row)")
     ap.add_argument("--scenario", default="PredatorCapturePrey")
     ap.add_argument("--dist-backend", default=None, help="nccl (default, = RCCL) | gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -607,7 +609,8 @@ def main():
                                "mean_return": float(rs.sum().item() / max(n_ep, 1)),
                                "mean_length": float(ss.sum().item() / max(n_ep, 1))}
         if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey":
-            out["graph_replay"] = graph_leg(env, dev, ptrs, min(K, 100))
+            if not args.no_graph:
+                out["graph_replay"] = graph_leg(env, dev, ptrs, min(K, 100))
             out["rollout"] = rollout_leg(env, dev, n_act, 777)
             out["saturated"] = saturated_leg(dev, overrides)
             out["saturated_2m"] = saturated_leg(dev, overrides, 4 * SATURATED_ENVS)

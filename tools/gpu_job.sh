@@ -20,9 +20,9 @@ for k in ("rollout", "saturated"):
     if k in d: print(k, "%.4g agent-steps/s, %.5f ms" % (d[k]["agent_steps_per_s"], d[k]["ms_per_step"]))
 PY
 if [[ " $* " != *" nopmc "* ]]; then
-  BENCH="python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline"
+  BENCH="python3 bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-graph"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1 || { tail -20 $OUT/kt.log; exit 3; }
-  BENCH="python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline"
+  BENCH="python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-graph"
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1 || { tail -20 $OUT/pmc_fetch.log; exit 4; }
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $BENCH > $OUT/pmc_write.log 2>&1 || { tail -20 $OUT/pmc_write.log; exit 5; }
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- $BENCH > $OUT/pmc_sq.log 2>&1 || { tail -20 $OUT/pmc_sq.log; exit 6; }
