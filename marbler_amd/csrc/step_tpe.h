@@ -58,6 +58,8 @@ __device__ __forceinline__ void for_pairs(F &&f) {
     });
 }
 
+// sums of the per-agent values pa, pb over the agents [LO, LO + W) present (< N) in the order of the lane-group kernel's butterfly
+// (oracle_core.h barrier_qp): block(LO, W) = block(LO, W/2) + block(LO + W/2, W/2); a right half of absent agents adds nothing
 template <int LO, int W, int N>
 __device__ __forceinline__ void block_sums(const float (&pa)[N], const float (&pb)[N], float &sa, float &sb) {
     if constexpr (W == 1) {
@@ -147,6 +149,9 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
             chg = fmaxf(chg, __builtin_fabsf(delta) * emax[i][j]);
             if constexpr (PHASE == 1) muA[i][j] = mn;
             if constexpr (PHASE == 2) muB[i][j] = mn;
+            // restart bookkeeping: the two inner products of the extrapolation factor, per agent over its partners in round order
+            // (for_pairs visits the pairs round by round), formed while the third sweep of a block runs -- as a pass of its own
+            // after the sweep the N = 6 instantiation spilled twice as many values (196 scratch instructions against 94, 20 % slower)
             if constexpr (PHASE == 3) {
                 const float d1 = muB[i][j] - muA[i][j], d2 = mn - muB[i][j];
                 const float dd = d2 - d1;
