@@ -33,8 +33,9 @@ struct rg_handle {
 // over where one of its steps undercuts the line.  Measured cross-overs on MI355X, final kernels of round 3
 // (tools/crossover_probe.py, profiles/r3_crossover_probe.txt): the sparse collision pre-test made
 // the lane-group kernel 5-8 % faster at these batch sizes and moved every threshold up from round 2's 53 248 / 65 536;
-// the one-division restart of the barrier QP then favoured the lane-group kernel again at N = 6, where the thread-per-env
-// kernel runs on spilled registers (non-MaterialTransport N = 6: 131 072 -> 262 144; Warehouse N = 6: lane-group at every size).
+// the one-division restart of the barrier QP then favoured the lane-group kernel at N = 6, where the thread-per-env kernel
+// runs on spilled registers, and compiling the thread-per-env files without the SLP vectoriser (build.py FILE_FLAGS: 57 fewer
+// spilled values at N = 6, -22 %) gave most of that back: the table below is the last measurement of round 3.
 // For N >= 7 the per-lane register footprint (28 pairs) leaves one wave per SIMD and the lane-group kernel -- at
 // 92 % VALU issue there -- stays ahead at every batch size.  RG_STEP_KERNEL=group|tpe forces one (tests, profiling).
 static int32_t tpe_min_envs(const rg_scenario_params &p) {
@@ -42,9 +43,9 @@ static int32_t tpe_min_envs(const rg_scenario_params &p) {
     switch (p.n_agents) {
         case 2: return 65536;
         case 3: return pcp ? 98304 : 65536;
-        case 4: return (p.scenario == RG_SCN_SIMPLE || p.scenario == RG_SCN_ARCTIC_TRANSPORT) ? 393216 : 196608;
+        case 4: return p.scenario == RG_SCN_SIMPLE ? 393216 : p.scenario == RG_SCN_ARCTIC_TRANSPORT ? 131072 : 196608;
         case 5: return mt ? 49152 : 65536;
-        case 6: return mt ? 98304 : p.scenario == RG_SCN_WAREHOUSE ? INT32_MAX : 262144;
+        case 6: return mt ? 65536 : p.scenario == RG_SCN_WAREHOUSE ? 262144 : pcp ? 98304 : 131072;
         default: return INT32_MAX;
     }
 }

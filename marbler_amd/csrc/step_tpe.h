@@ -237,8 +237,19 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
 // the fences only pin the compiler's order.
 // 16 KB: eight one-wave workgroups per CU (two waves per SIMD) fit the CU's 160 KB; 12 KB for the instantiations that
 // run three waves per SIMD (N <= 4: twelve workgroups per CU)
+#ifndef RG_TPE_W4
+#define RG_TPE_W4 3   // waves per SIMD the N <= 4 instantiations are compiled for
+#endif
+#ifndef RG_TPE_W5
+#define RG_TPE_W5 0   // N = 5 (0 = the compiler's own allocation: two)
+#endif
+#ifndef RG_TPE_W78
+#define RG_TPE_W78 1  // N = 7, 8
+#endif
+constexpr int tpe_waves(int n) { return n <= 4 ? RG_TPE_W4 : n == 5 ? RG_TPE_W5 : n == 6 ? 2 : RG_TPE_W78; }
+// the wave's LDS block in floats: as many one-wave workgroups as the SIMDs' wave slots must fit a CU's 160 KB
 template <int N>
-constexpr int stage_dw() { return N <= 4 ? 3072 : 4096; }
+constexpr int stage_dw() { return tpe_waves(N) >= 4 ? 2560 : tpe_waves(N) == 3 ? 3072 : 4096; }
 typedef float f4v __attribute__((ext_vector_type(4), may_alias));
 typedef float f2v __attribute__((ext_vector_type(2), may_alias));
 
@@ -1089,14 +1100,14 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 
 // ------------------------------------------------------------------ the step kernel
 template <int SCN, int N, bool ROLLOUT>
-// (forcing the register budget of 3 waves per SIMD with amdgpu_waves_per_eu spills ~100 VGPRs at N = 5
-// and measured 1.7x slower; the natural allocation runs 2 waves per SIMD at N = 5, 6 and 3 at N <= 4)
+// Waves per SIMD (tpe_waves above; these files are compiled without the SLP vectoriser, build.py FILE_FLAGS, which alone
+// took N = 5 from 244 to 203 VGPRs, N <= 4 from 168 + 7 spilled to 147 and N = 6 from 76 to 19 spilled values): N <= 4
+// three, N = 5 two -- both now the compiler's own allocation --, N = 6 two on a forced 256-register budget (19 values in
+// scratch; one wave per SIMD measured 34 % slower in round 2), N >= 7 one.  Measured and rejected in round 3 at 524 288 envs
+// (tools/tpe_ab_probe.py, -DRG_TPE_W5=3 / -DRG_TPE_W4=4 / -DRG_TPE_W78=2): N = 5 at three waves (32 spilled) 169.6 vs
+// 153.1 us, N = 4 at four (18 spilled) 108.7 vs 99.5, N = 7 at two (93 spilled) 390.6 vs 348.0, N = 8 at two 1448 vs 481.
 #ifndef RG_TPE_NO_W3
-// Occupancy bought with a few scratch slots where the natural allocation misses a wave by a small margin (measured at
-// 524 288 envs, tools/n4_probe.py): N <= 4 needs 170-180 VGPRs, 168 give three waves per SIMD (5-8 values spilled:
-// +4..14 %); N = 6 needs 256 + 40, 256 give two (28-48 spilled: +21..34 %).  N = 5 fits two as it is, and three would
-// spill ~100 (1.7x slower); N >= 7 would spill 130+ and stays on the lane-group kernel.
-__attribute__((amdgpu_waves_per_eu(N <= 4 ? 3 : N == 6 ? 2 : 1)))
+__attribute__((amdgpu_waves_per_eu(tpe_waves(N) ? tpe_waves(N) : 1)))
 #endif
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ union alignas(16) {
@@ -1144,13 +1155,19 @@ static hipError_t launch_scn(const KernelArgs &a, hipStream_t stream) {
     case NN:                                                                                          \
         hipLaunchKernelGGL((step_kernel<SCN, NN, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);             \
         break;
+#ifndef RG_TPE_HI  // robogym_tpe.hip / robogym_rollout_tpe.hip: the instantiations the library dispatches to (N <= 6)
         RG_CASE(2)
         RG_CASE(3)
         RG_CASE(4)
         RG_CASE(5)
         RG_CASE(6)
-        RG_CASE(7)
+        case 7:
+        case 8:
+            return ROLLOUT ? launch_rollout_tpe_hi(a, stream) : launch_step_tpe_hi(a, stream);
+#else              // robogym_tpe_hi.hip / robogym_rollout_tpe_hi.hip: N = 7, 8 (reachable with RG_STEP_KERNEL=tpe only), built with
+        RG_CASE(7)  // other flags than the files above (build.py FILE_FLAGS)
         RG_CASE(8)
+#endif
 #undef RG_CASE
         default:
             return hipErrorInvalidValue;
@@ -1171,11 +1188,13 @@ static hipError_t launch_tpe(const KernelArgs &a, hipStream_t stream) {
             return tpe::launch_scn<RG_SCN_MATERIAL_TRANSPORT, ROLLOUT>(a, stream);
         case RG_SCN_SIMPLE:
             return tpe::launch_scn<RG_SCN_SIMPLE, ROLLOUT>(a, stream);
+#ifndef RG_TPE_HI
         case RG_SCN_ARCTIC_TRANSPORT: {
             const int grid = (a.E + WAVE - 1) / WAVE;
             hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
             return hipGetLastError();
         }
+#endif
         default:
             return hipErrorInvalidValue;
     }

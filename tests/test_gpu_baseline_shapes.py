@@ -160,10 +160,10 @@ def shape_rollout_vs_oracle(name, scenario, ov, n_act, E, steps, slots, oracle_l
     ("PredatorCapturePrey", {"predator": 2, "capture": 1, "n_agents": 3}, 98304),
     ("PredatorCapturePrey", {}, 196608),                                                   # the reference's default: 4 agents
     ("Simple", {}, 393216),
-    ("MaterialTransport", MT6, 98304),
+    ("MaterialTransport", MT6, 65536),
     ("MaterialTransport", {"n_agents": 5, "n_fast_agents": 3, "n_slow_agents": 2, "start_dist": 0.25}, 49152),
-    ("Warehouse", {}, None),                                                               # default: 6 agents: lane-group at every size
-    ("PredatorCapturePrey", {"predator": 3, "capture": 3, "n_agents": 6}, 262144),
+    ("Warehouse", {}, 262144),                                                             # default: 6 agents
+    ("PredatorCapturePrey", {"predator": 3, "capture": 3, "n_agents": 6}, 98304),
     ("Warehouse", WH8, None),                                                              # N >= 7: never
 ])
 def test_kernel_choice_follows_the_measured_cross_overs(scenario, ov, threshold, monkeypatch):

@@ -8,6 +8,8 @@ import torch
 from marbler_amd import VecRobotariumEnv
 CFG = {4: [("PredatorCapturePrey", {"predator": 2, "capture": 2, "n_agents": 4}, 5), ("MaterialTransport", {}, 20)],
        5: [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5)],
+       7: [("Warehouse", {"n_agents": 7}, 5)],
+       8: [("Warehouse", {"n_agents": 8}, 5)],
        6: [("PredatorCapturePrey", {"predator": 3, "capture": 3, "n_agents": 6}, 5),
            ("MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25}, 20),
            ("Warehouse", {"n_agents": 6}, 5)]}
