@@ -32,7 +32,15 @@ ARCH = "gfx950"
 # vectoriser, with -O2 -fno-slp-vectorize, and fails again when compiled for two waves per SIMD).  Neither a use of
 # undefined behaviour in the source nor a hardware hazard was found in the time available; until it is explained those two
 # files stay on the flags every test and 250 M fuzzed env steps have covered.
-FILE_FLAGS = {"robogym_tpe.hip": ["-fno-slp-vectorize"], "robogym_rollout_tpe.hip": ["-fno-slp-vectorize"]}
+# The lane-group kernels get the opposite treatment: -mllvm -slp-threshold=-60 makes the vectoriser pack wherever it can (1 083 ->
+# 1 227 packed f32 instructions per translation unit) instead of where its cost model sees a profit -- on a dependent chain at one
+# wave per SIMD every instruction saved is ~5 cycles: headline launch 13.16 -> 12.73 us, Warehouse 4096 x 8 12.59 -> 12.40,
+# rg_rollout 8.23 -> 7.97 us per step; the MaterialTransport N = 6 instantiation grows from 128 to 130 VGPRs (four waves per SIMD
+# -> three), which costs 3.5 % at 32 768 x 6 envs, a size between the BASELINE shapes (2048 / 4096 x 6: -0.4 %).  Thresholds
+# -12 / -24 / -60 / -200 measured within 1 % of each other (tools/ab_job.sh).
+GROUP_SLP = ["-mllvm", "-slp-threshold=-60"]
+FILE_FLAGS = {"robogym_tpe.hip": ["-fno-slp-vectorize"], "robogym_rollout_tpe.hip": ["-fno-slp-vectorize"],
+              "robogym_kernels.hip": GROUP_SLP, "robogym_rollout_group.hip": GROUP_SLP}
 
 
 def hipcc_path():

@@ -18,7 +18,7 @@ def _report(src, defines=()):
         hipcc = hip_build.hipcc_path()
     except RuntimeError:
         pytest.skip("no hipcc")
-    extra = hip_build.FILE_FLAGS["robogym_tpe.hip"] if src.startswith("tpe_") else []      # the flags the library is built with
+    extra = hip_build.FILE_FLAGS["robogym_tpe.hip" if src.startswith("tpe_") else "robogym_kernels.hip"]   # the flags the library is built with
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, *extra,
                         "-Rpass-analysis=kernel-resource-usage", *[f"-D{d}" for d in defines],
                         "-c", os.path.join(ROOT, "tests", "kernels", src),
