@@ -30,7 +30,8 @@ ARCH = "gfx950"
 # keep the default flags: built with -O3 -fno-slp-vectorize, ONE of them -- MaterialTransport, N = 7 -- computes wrong poses
 # from the first step on (5 of 935 GPU tests; every other instantiation passes; the same source passes with -O3 and the
 # vectoriser, with -O2 -fno-slp-vectorize, and fails again when compiled for two waves per SIMD; with -fno-strict-aliasing
-# -fwrapv -fno-delete-null-pointer-checks added it passes and PredatorCapturePrey N = 7 fails instead: it is N = 7 that is sensitive).  Neither a use of
+# -fwrapv -fno-delete-null-pointer-checks added it passes and PredatorCapturePrey N = 7 fails instead: it is N = 7 that is sensitive; capped at one QP
+# sweep the failing kernel returns a float's bit pattern in its integer sweep counter: a register-assignment matter).  Neither a use of
 # undefined behaviour in the source nor a hardware hazard was found in the time available; until it is explained those two
 # files stay on the flags every test and 250 M fuzzed env steps have covered.
 # The lane-group kernels get the opposite treatment: -mllvm -slp-threshold=-60 makes the vectoriser pack wherever it can (1 083 ->
