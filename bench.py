@@ -591,8 +591,8 @@ def main():
                                          "of the 8 XCD L2s per launch (profiles/r3_fetch_floor_pmc_summary.csv)",
                          "traffic_source": counters_src, "valu": valu,
                          "kernel": (f"rg::step_kernel<{args.scenario},GW={4 if N <= 4 else 8 if N <= 8 else 16},N={N}> (lane group per env)"
-                                    if (args.scenario != "PredatorCapturePrey" or E < 65536)
-                                    else "rg::tpe::step_kernel<PCP,N=5> (one lane per env)"),
+                                    if env.step_kernel == "group"
+                                    else f"rg::tpe::step_kernel<{args.scenario},N={N}> (one lane per env)"),
                          "kernel_ms_avg": gpu_ms_total / K,   # HIP events around the timed region / K (back-to-back launches)
                          "kernel_ms_avg_event_pair_per_launch": kernel_ms,
                          "kernel_ms_median_event_pair_per_launch": kernel_ms_median,

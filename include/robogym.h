@@ -217,8 +217,8 @@ int rg_set_stream(rg_handle *h, void *hip_stream);
  * where get_obs() lives).  obs: [E][N][D]. */
 int rg_get_obs(rg_handle *h, float *obs);
 
-/* Which step kernel this handle launches: 0 = lane group per env (small / medium batches, N >= 7), 1 = one lane per env
- * (chip-filling batches).  Chosen in rg_create from (scenario, n_agents, num_envs) -- measured cross-overs, csrc/robogym_capi.hip
+/* Which step kernel this handle launches: 0 = lane group per env (small / medium batches, and N >= 7 at every batch size:
+ * the one-lane-per-env kernel is instantiated for N <= 6 only since round 4), 1 = one lane per env (chip-filling batches).  Chosen in rg_create from (scenario, n_agents, num_envs) -- measured cross-overs, csrc/robogym_capi.hip
  * tpe_min_envs -- or forced by the environment variable RG_STEP_KERNEL=group|tpe.  Both give bit-identical results; the
  * query exists so that tests and profiles can say which one ran.  Negative: error. */
 int rg_step_kernel(const rg_handle *h);

@@ -14,35 +14,32 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librobogym_hip.so")
-SOURCES = ["robogym_kernels.hip", "robogym_rollout_group.hip", "robogym_tpe.hip", "robogym_rollout_tpe.hip",
-           "robogym_tpe_hi.hip", "robogym_rollout_tpe_hi.hip", "robogym_capi.hip", "actor_mfma.hip"]
+SOURCES = ["robogym_kernels.hip", "robogym_rollout_group.hip", "robogym_tpe.hip", "robogym_rollout_tpe.hip", "robogym_capi.hip",
+           "actor_mfma.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("sim_math.h", "kernel_args.h", "device_common.h", "step_group.h", "step_tpe.h")] + \
           [os.path.join(HERE, "..", "include", "robogym.h")]
 ARCH = "gfx950"
-# Per-file flags.  The thread-per-env kernels are compiled WITHOUT the SLP vectoriser: left on, it pairs the x / y halves of
-# the float arithmetic into v_pk_{add,mul,fma}_f32, which need even-aligned register pairs (more spills at N = 6, a kernel
-# already compiled onto a register budget) and issue no faster than the two scalar instructions on gfx950 -- measured at
-# 524 288 envs: N = 6 272 -> 213 us (-22 %), MaterialTransport N = 6 473 -> 386, N = 5 158.5 -> 152.1, N = 4 99 -> 94.  The
-# lane-group kernels keep it: there one wave per SIMD runs a dependent chain, fewer instructions on the chain win, and the
-# same flag makes the headline launch 4.6 % SLOWER (13.24 -> 13.85 us).  Results are bit-identical either way (same IEEE
-# operations); tools/ab_job.sh / tools/tpe_ab_probe.py with RG_EXTRA_HIPCC_FLAGS=-fno-slp-vectorize is how it was measured.
-# The N = 7, 8 instantiations (robogym_*tpe_hi.hip: never dispatched by the library, reachable with RG_STEP_KERNEL=tpe only)
-# keep the default flags: built with -O3 -fno-slp-vectorize, ONE of them -- MaterialTransport, N = 7 -- computes wrong poses
-# from the first step on (5 of 935 GPU tests; every other instantiation passes; the same source passes with -O3 and the
-# vectoriser, with -O2 -fno-slp-vectorize, and fails again when compiled for two waves per SIMD; with -fno-strict-aliasing
-# -fwrapv -fno-delete-null-pointer-checks added it passes and PredatorCapturePrey N = 7 fails instead: it is N = 7 that is sensitive; capped at one QP
-# sweep the failing kernel returns a float's bit pattern in its integer sweep counter: a register-assignment matter).  Neither a use of
-# undefined behaviour in the source nor a hardware hazard was found in the time available; until it is explained those two
-# files stay on the flags every test and 250 M fuzzed env steps have covered.
-# The lane-group kernels get the opposite treatment: -mllvm -slp-threshold=-60 makes the vectoriser pack wherever it can (1 083 ->
-# 1 227 packed f32 instructions per translation unit) instead of where its cost model sees a profit -- on a dependent chain at one
-# wave per SIMD every instruction saved is ~5 cycles: headline launch 13.16 -> 12.73 us, Warehouse 4096 x 8 12.59 -> 12.40,
-# rg_rollout 8.23 -> 7.97 us per step; the MaterialTransport N = 6 instantiation grows from 128 to 130 VGPRs (four waves per SIMD
-# -> three), which costs 3.5 % at 32 768 x 6 envs, a size between the BASELINE shapes (2048 / 4096 x 6: -0.4 %).  Thresholds
-# -12 / -24 / -60 / -200 measured within 1 % of each other (tools/ab_job.sh).
+# Per-file flags (results are bit-identical either way: the same IEEE operations; tools/ab_job.sh measured them).
+# * thread-per-env kernels: WITHOUT the SLP vectoriser.  Left on, it pairs the x / y halves of the float arithmetic into
+#   v_pk_{add,mul,fma}_f32, which need even-aligned register pairs (more spills at N = 6, a kernel already compiled onto a
+#   register budget) and issue no faster than the two scalar instructions on gfx950: N = 6 272 -> 213 us (-22 %) at 524 288 envs,
+#   MaterialTransport N = 6 473 -> 386, N = 5 158.5 -> 152.1, N = 4 99 -> 94.
+# * lane-group kernels: the opposite, -mllvm -slp-threshold=-60 (pack wherever possible; 1 083 -> 1 227 packed f32 instructions
+#   per translation unit): one wave per SIMD runs a dependent chain and every instruction saved is ~5 cycles -- headline launch
+#   13.16 -> 12.73 us, Warehouse 4096 x 8 12.59 -> 12.40, rg_rollout 8.23 -> 7.97 us per step.
+# Round 3 found that ONE thread-per-env instantiation (MaterialTransport, N = 7) computes wrong poses under
+# -O3 -fno-slp-vectorize.  Round 4 found why (tools/n7_bisect/): ROCm 7.2's register allocator placed
+# VGPR -> AGPR live-range split copies at the top of an `if`'s join block BEFORE the `s_or_b64 exec` that restores the exec
+# mask -- an SGPR copy of the earlier SGPR allocation sat in front of it and ended what LLVM takes for the block prologue --
+# so the saves ran for the `then` lanes only.  A compiler defect, not a property of this source (the same source is clean
+# under ASan / UBSan / MSan on the host, tests/test_sanitizers.py); whether a build has it is visible in the ISA, and
+# tests/test_kernel_resources.py scans every kernel of the shipped library for it (tools/isa_scan.py exec_prologue).
+# The N = 7, 8 instantiations were never dispatched and are no longer built.
 GROUP_SLP = ["-mllvm", "-slp-threshold=-60"]
 FILE_FLAGS = {"robogym_tpe.hip": ["-fno-slp-vectorize"], "robogym_rollout_tpe.hip": ["-fno-slp-vectorize"],
               "robogym_kernels.hip": GROUP_SLP, "robogym_rollout_group.hip": GROUP_SLP}
+BASE_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+STAMP = LIB + ".flags"
 
 
 def hipcc_path():
@@ -52,29 +49,49 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (ROCm 7.x expected under /opt/rocm)")
 
 
+def flags_stamp(defines=(), extra=(), file_flags=True):
+    """What a library was built with, as one string: the rebuild check compares it (a library left behind by an A/B build
+    with other flags is stale, whatever its mtime)."""
+    per_file = sorted(FILE_FLAGS.items()) if file_flags else []
+    return repr((BASE_FLAGS, sorted(defines), list(extra), per_file, SOURCES))
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    try:
+        with open(STAMP) as f:
+            return f.read() != flags_stamp()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False, defines=(), out=None):
-    """defines / out: diagnostic variants (e.g. defines=("RG_STAMPS",), out=".../librobogym_stamps.so")."""
+    """defines / out: diagnostic variants (e.g. defines=("RG_STAMPS",), out=".../librobogym_stamps.so").  The environment
+    variables RG_EXTRA_HIPCC_FLAGS / RG_NO_FILE_FLAGS (A/B builds, tools/ab_job.sh) apply to such variants only: the shipped
+    library is always built with the flags above."""
+    extra = os.environ.get("RG_EXTRA_HIPCC_FLAGS", "").split()
+    no_file_flags = bool(os.environ.get("RG_NO_FILE_FLAGS"))
+    if out is None and (extra or no_file_flags):
+        raise RuntimeError("RG_EXTRA_HIPCC_FLAGS / RG_NO_FILE_FLAGS are for diagnostic variants (build(out=...)): "
+                           "the shipped library's flags are fixed in marbler_amd/build.py")
     if out is None and not force and not needs_build():
         return LIB
+    shipped = out is None
     out = out or LIB
     # one object per translation unit, compiled side by side (the kernel instantiations dominate:
     # ~2 min each for the lane-group files, ~1 min for the thread-per-env ones), then one link
     objdir = os.path.join(HERE, "build", os.path.splitext(os.path.basename(out))[0])
     os.makedirs(objdir, exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
-             "-Wno-unused-function"] + [f"-D{d}" for d in defines] + list(os.environ.get("RG_EXTRA_HIPCC_FLAGS", "").split())
+    flags = BASE_FLAGS + [f"-D{d}" for d in defines] + extra
     objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        per_file = [] if os.environ.get("RG_NO_FILE_FLAGS") else FILE_FLAGS.get(src, [])   # (A/B builds)
+        per_file = [] if no_file_flags else FILE_FLAGS.get(src, [])   # (A/B builds)
         cmd = [hipcc_path()] + flags + per_file + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -87,6 +104,8 @@ def build(force=False, verbose=False, defines=(), out=None):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    with open(out + ".flags", "w") as f:
+        f.write(flags_stamp(defines, extra, not no_file_flags) if not shipped else flags_stamp())
     return out
 
 

@@ -92,6 +92,10 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 template <int K>
 __device__ __forceinline__ void dot2_batch(int (&d)[K]) {
     static_assert(K >= 1, "at least one");
+#ifdef RG_HOST_SIM  // host simulation under the CPU sanitizers (tests/sanitize/): the same dot products in C
+    for (int i = 0; i < K; ++i) d[i] = rg_sim_dot2_self(d[i]);
+    return;
+#endif
     if constexpr (K >= 4) {
         asm("v_dot2_f32_f16 %0, %0, %0, 0\n\tv_dot2_f32_f16 %1, %1, %1, 0\n\tv_dot2_f32_f16 %2, %2, %2, 0\n\t"
             "v_dot2_f32_f16 %3, %3, %3, 0\n\ts_nop 2"

@@ -127,8 +127,5 @@ hipError_t launch_step_tpe(const KernelArgs &a, hipStream_t stream);
 // rg_rollout: num_steps env steps per launch (robogym_rollout_group.hip, robogym_rollout_tpe.hip)
 hipError_t launch_rollout(const KernelArgs &a, hipStream_t stream);
 hipError_t launch_rollout_tpe(const KernelArgs &a, hipStream_t stream);
-// the N = 7, 8 instantiations of the thread-per-env kernels live in translation units of their own (robogym_*tpe_hi.hip)
-hipError_t launch_step_tpe_hi(const KernelArgs &a, hipStream_t stream);
-hipError_t launch_rollout_tpe_hi(const KernelArgs &a, hipStream_t stream);
 
 }  // namespace rg

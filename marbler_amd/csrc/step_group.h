@@ -56,6 +56,7 @@ __device__ __forceinline__ void out_store1(float *p, float a) {
 // sub-steps validated together (ILP across independent test chains).  The controller periods of the
 // reference's configurations are 15 and 14 sub-steps: three chunks of 5, or two and a remainder chunk of 4.
 constexpr int CHUNK = RG_CHUNK;
+static_assert(CHUNK >= 1 && CHUNK <= 5, "the sparse collision pre-test covers sub-steps 0..2 and 3..4 of a chunk: longer chunks would go untested");
 
 // ------------------------------------------------------------------ controller (a3..a8)
 // utilities/controller.py:20-24 over the restated rps closures,
@@ -663,7 +664,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             // passes it cannot be within the collision distance at any of them.  A chunk tests sub-steps 0 (covering 0..2)
             // and 3 (covering the rest) instead of all five; only a chunk that fails goes on to the per-sub-step pre-test
             // and, from there, to the exact replay -- the masks come from the exact test alone, results are unchanged.
-            const float mstep = lane_ok ? __builtin_fmaf(k.coll_off, __builtin_fabsf(dtw), __builtin_fabsf(dtv)) * 1.00001f : 0.0f;
+            const float mstep = lane_ok ? __builtin_fmaf(__builtin_fabsf(k.coll_off), __builtin_fabsf(dtw), __builtin_fabsf(dtv)) * 1.00001f : 0.0f;
             const float M2 = 2.0f * group_max_nonneg<GW>(mstep);
             auto thr_span = [&](int span) {  // bits of the squared threshold (non-negative floats order like their bit patterns)
                 const float t = (k.lin_pre + PRE_SLACK) + static_cast<float>(span) * M2;

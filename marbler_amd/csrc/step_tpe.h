@@ -16,7 +16,7 @@
 //
 // With one wave per SIMD up to 65 536 envs the launch time is flat (one wave's chain), beyond that
 // the kernel is VALU-issue bound.  Registers are not a constraint at <= 1 wave per SIMD (512 VGPRs).
-// The host picks this kernel for N <= 8 and E >= RG_TPE_MIN_ENVS (robogym_capi.hip).
+// The host picks this kernel for N <= 6 and E >= tpe_min_envs (robogym_capi.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -452,8 +452,9 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     // field at its first use; see step_group.h), then ALL the loads before anything waits for one of them
     const float *q_poses = a.st.poses, *q_carry = a.st.carry_dist, *q_ret = a.st.ep_return, *q_sum = a.st.done_return_sum;
     const int32_t *q_steps = a.st.episode_steps, *q_act = sv.actions, *q_cnt = a.st.done_count, *q_stp = a.st.done_steps_sum;
+#ifndef RG_HOST_SIM  // (scheduling hint only; the host simulation of tests/sanitize/ has no "s" registers)
     asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp));
-#define RG_LATE(v) asm volatile("" : "+v"(v))
+#endif
     float x[N], y[N], th[N], acc[N], last[N];
     int act[N];
     int pix[N];
@@ -1119,7 +1120,11 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     // All 64 lanes run the step (the staged stores are copied out by the whole wave): lanes past the end of the batch
     // repeat its last env -- the same loads, the same values, the same stores -- and take no part in the fused reset.
     const int e_raw = chunk * WAVE + threadIdx.x;
+#ifndef RG_HOST_SIM
     const int e = e_raw < a.E ? e_raw : a.E - 1;
+#else  // host simulation (tests/sanitize/): lanes are threads, not in lock step, so the surplus lanes of the last wave cannot share
+    const int e = e_raw;  // env E - 1's read-modify-writes; the harness pads every array to whole waves with copies of that env
+#endif
     const int left = a.E - chunk * WAVE;
 #ifdef RG_TPE_GUARD
     const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE,
@@ -1155,19 +1160,14 @@ static hipError_t launch_scn(const KernelArgs &a, hipStream_t stream) {
     case NN:                                                                                          \
         hipLaunchKernelGGL((step_kernel<SCN, NN, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);             \
         break;
-#ifndef RG_TPE_HI  // robogym_tpe.hip / robogym_rollout_tpe.hip: the instantiations the library dispatches to (N <= 6)
+        // N <= 6: the agent counts the library dispatches this kernel for.  N = 7, 8 compile (tools/n7_bisect/, tests/sanitize/) but are
+        // not part of the library since round 4: never chosen (the lane-group kernel is faster there at every batch size), and the
+        // one instantiation the ROCm 7.2 register allocator miscompiled under some flags.
         RG_CASE(2)
         RG_CASE(3)
         RG_CASE(4)
         RG_CASE(5)
         RG_CASE(6)
-        case 7:
-        case 8:
-            return ROLLOUT ? launch_rollout_tpe_hi(a, stream) : launch_step_tpe_hi(a, stream);
-#else              // robogym_tpe_hi.hip / robogym_rollout_tpe_hi.hip: N = 7, 8 (reachable with RG_STEP_KERNEL=tpe only), built with
-        RG_CASE(7)  // other flags than the files above (build.py FILE_FLAGS)
-        RG_CASE(8)
-#endif
 #undef RG_CASE
         default:
             return hipErrorInvalidValue;
@@ -1188,13 +1188,11 @@ static hipError_t launch_tpe(const KernelArgs &a, hipStream_t stream) {
             return tpe::launch_scn<RG_SCN_MATERIAL_TRANSPORT, ROLLOUT>(a, stream);
         case RG_SCN_SIMPLE:
             return tpe::launch_scn<RG_SCN_SIMPLE, ROLLOUT>(a, stream);
-#ifndef RG_TPE_HI
         case RG_SCN_ARCTIC_TRANSPORT: {
             const int grid = (a.E + WAVE - 1) / WAVE;
             hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
             return hipGetLastError();
         }
-#endif
         default:
             return hipErrorInvalidValue;
     }

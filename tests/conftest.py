@@ -22,7 +22,7 @@ def oracle_lib():
 @pytest.fixture(params=["group", "tpe"])
 def step_kernel(request, monkeypatch):
     """Runs a GPU test once per step kernel (lane-group / thread-per-env; rg_create reads
-    RG_STEP_KERNEL).  Configurations the thread-per-env kernel does not cover (N > 8) run the
+    RG_STEP_KERNEL).  Configurations the thread-per-env kernel does not cover (N > 6) run the
     lane-group kernel in both instances."""
     monkeypatch.setenv("RG_STEP_KERNEL", request.param)
     return request.param
