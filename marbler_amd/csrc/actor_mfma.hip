@@ -45,8 +45,18 @@ struct ActorArgs {
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
+#ifdef RG_ACTOR_STAMPS  // diagnostic build (tools/actor_stamps.py): wave-cycle stamps of the phases, written over q
+#define RG_ASTAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
+#else
+#define RG_ASTAMP(i)
+#endif
+
 template <int H>
 __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
+#ifdef RG_ACTOR_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     constexpr int HP = H + 4;  // LDS row pitch (floats): rows 16 B aligned, bank-staggered
     constexpr int NTHREADS = 64 * (H / 32);
     __shared__ __attribute__((aligned(16))) float Xs[TM][MAX_IP + 4];
@@ -95,6 +105,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         *reinterpret_cast<float4 *>(&Hs[i][4 * k4]) = v;
     }
     __syncthreads();
+    RG_ASTAMP(0);  // inputs staged
 
     auto zero16 = [] {
         floatx16 z;
@@ -132,6 +143,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         for (int r = 0; r < 16; ++r) Y1[crow(r)][n] = fmaxf(acc[r] + b, 0.0f);
     }
     __syncthreads();
+    RG_ASTAMP(1);  // fc1
 
     // ---- recurrent layer
     float hn[16];       // the new hidden state in accumulator layout (the old one is still an operand)
@@ -188,6 +200,11 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) wcur[q4] = wnext[q4];
             }
+#ifdef RG_ACTOR_STAMPS
+#pragma unroll
+            for (int g = 0; g < 3; ++g) asm volatile("" ::"v"(gi[g]), "v"(gh[g]));
+            RG_ASTAMP(2);  // GRU products
+#endif
             const float bir = Bih[j], biz = Bih[H + j], bin = Bih[2 * H + j];
             const float bhr = Bhh[j], bhz = Bhh[H + j], bhn = Bhh[2 * H + j];
 #pragma unroll
@@ -212,6 +229,11 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             for (int r = 0; r < 16; ++r) hn[r] = fmaxf(acc[r] + b, 0.0f);
         }
     }
+#ifdef RG_ACTOR_STAMPS
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(hn[r]));
+    RG_ASTAMP(3);  // gates
+#endif
     __syncthreads();  // every read of the old hidden state is done
     {
         const int j = cb * 32 + col;
@@ -223,6 +245,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         }
     }
     __syncthreads();
+    RG_ASTAMP(4);  // new hidden state stored
 
     // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one tile, wavefront 0), then the greedy action per row
     if (cb == 0) {
@@ -239,6 +262,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         for (int r = 0; r < 16; ++r) Y1[crow(r)][col] = acc[r] + b;  // Y1 is free again: the q tile, row-major
     }
     __syncthreads();
+    RG_ASTAMP(5);  // fc2
     if (tid < TM && row_ok(tid)) {
         const int r = row_of(tid);
         float best = Y1[tid][0];
@@ -253,6 +277,14 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         }
         if (a.actions) a.actions[r] = arg;
     }
+#ifdef RG_ACTOR_STAMPS
+    RG_ASTAMP(6);
+    __syncthreads();
+    if (lane == 0 && a.q) {
+        int *dst = reinterpret_cast<int *>(a.q) + (static_cast<size_t>(blockIdx.x) * (H / 32) + cb) * 8;
+        for (int i = 0; i < 8; ++i) dst[i] = stamps[i];
+    }
+#endif
 }
 
 // torch layout [S][3H][H] -> the kernel's streaming order [S][cb][chunk][gate][q4][lane = (half, col)][4]
