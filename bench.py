@@ -402,16 +402,20 @@ def dry_run(args, rank, world, collective):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_rank = [elapsed * 1e3]
+    if world > 1:   # the same gather of every rank's own time as the measured run (per_rank_ms_per_step), then the max
+        mine = torch.tensor([elapsed * 1e3], dtype=torch.float64)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = [float(v[0]) for v in everyone]
+        elapsed = max(per_rank) * 1e-3
     zeros_f, zeros_i = torch.zeros(count), torch.full((count,), rank, dtype=torch.int32)
     stats = rgdist.gather_episode_stats(zeros_f, zeros_i, zeros_i.clone(), dst=0)
     if rank == 0:
         import hashlib
         out = {"metric": "env agent-steps/sec", "value": None, "unit": "agent-steps/s", "n_gpus": world, "steps": 0,
                "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "per_rank_ms_per_step": per_rank,   # (dry run: each rank's time in the barrier, to exercise the gather)
                "dtype": "f32", "data": "none (dry run: no GPU work)", "dry_run": True,
                "config": {"workload": f"{args.scenario}-v0, {E} envs x {params.n_agents} agents per GPU (dry run)",
                           "envs_per_gpu": E, "agents": int(params.n_agents), "parallelism": f"env-sharded x{world}"},
@@ -536,10 +540,15 @@ def main():
     barrier()
     assert rc == 0
     gpu_ms_total = ev0.elapsed_time(ev1)
+    # every rank's own clock and its own HIP-event time, so that a slow N-GPU line says WHICH rank was slow (the value is
+    # still computed from the max over ranks, as the contract asks)
+    per_rank = [[elapsed / K * 1e3, gpu_ms_total / K]]
     if grouped:
-        t = torch.tensor([elapsed], device=rgdist.collective_device(dev), dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor(per_rank[0], device=rgdist.collective_device(dev), dtype=torch.float64)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = [[float(v[0]), float(v[1])] for v in everyone]
+        elapsed = max(v[0] for v in per_rank) * K * 1e-3
 
     # ---- roofline leg: the same launches with a HIP event pair around each (stream = the launch stream)
     n_probe = min(K, 300)
@@ -578,6 +587,7 @@ def main():
         out = {
             "metric": "env agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "per_rank_ms_per_step": [round(v[0], 6) for v in per_rank], "per_rank_kernel_ms_per_step": [round(v[1], 6) for v in per_rank],
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scenario}-v0, {E} envs x {N} agents per GPU, random policy, "
                                    f"auto-reset, update_frequency {env.params.update_frequency}, one rg_step launch per env step",

@@ -301,9 +301,10 @@ int rg_rollout(rg_handle *h, const int32_t *actions, int32_t num_steps, const rg
     if (num_steps < 1) return fail(-27, "num_steps < 1");
     if (io->elapsed) return fail(-29, "the gymma block of rg_step_io belongs to rg_step (one launch per step)");
     if (int rc = check_io(io)) return rc;
-    // every step's [E][N][D] slice must keep the 16-byte alignment of the block stores
-    if ((static_cast<size_t>(h->num_envs) * h->params.n_agents * h->params.obs_dim) & 3u)
-        return fail(-26, "E*N*D must be a multiple of 4 for rg_rollout");
+    // (Until round 4 every step's [E][N][D] slice had to keep 16-byte alignment.  Not needed: the only 16-byte observation stores
+    // are the 4-float blocks of PredatorCapturePrey without capabilities, whose D is a multiple of 4 -- every slice of that
+    // format is aligned whatever E and N are; all other formats are written dword by dword, and the staged copies of the
+    // thread-per-env kernel test their destination's alignment themselves (step_tpe.h copy_span / stage_obs_rows).)
     a.actions = actions;
     a.io = *io;
     a.num_steps = num_steps;

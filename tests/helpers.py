@@ -13,8 +13,9 @@ FLAT = ("goal_col",)
 
 
 def golden_files():
-    """Step fixtures (the actor_*.npz files are the policy-network vectors of tests/test_evaluate.py)."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith("actor_"))
+    """Step fixtures (the actor_*.npz files are the policy-network vectors of tests/test_evaluate.py, zoo_eval_replay.npz the
+    recorded policy rollouts of tests/test_zoo_eval.py)."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith(("actor_", "zoo_")))
 
 
 def load_golden(path):

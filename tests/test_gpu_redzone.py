@@ -132,7 +132,7 @@ def test_no_store_outside_the_bound_arrays(name, scenario, ov, n_act, kernel, mo
         bad = env.red_zones_intact()
         assert bad.size == 0, (f"{name} E={E} kernel={kernel}: rg_step damaged {bad.size} red-zone bytes, first at slab offset "
                                f"{int(bad[0])} (after `{env.owner_of(int(bad[0]))}`)")
-        if (E * env.N * env.D) % 4 == 0:   # rg_rollout's alignment rule
+        if True:   # (every shape since round 4: rg_rollout no longer asks for E*N*D % 4 == 0)
             out1 = env.rollout(acts[STEPS:])
             out2 = ref.rollout(acts[STEPS:])
             for key in ("obs", "reward", "done", "dist_travelled", "violation", "remaining"):

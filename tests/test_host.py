@@ -233,6 +233,7 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True and d["value"] is None
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(v >= 0 for v in d["per_rank_ms_per_step"])   # one entry per rank, gathered
     assert d["collective"] == {"backend": "gloo", "world_size": 2, "ranks_seen": [0, 1],
                                "library": "gloo over TCP loopback (rehearsal)"}
     assert d["gathered_envs"] == 2 * 4096 and d["gathered_rank_ids"] == [0, 1] and d["shard_of_rank_0"] == [0, 4096]

@@ -42,9 +42,8 @@ struct ActorArgs {
 
 // gate nonlinearities on the hardware exponential (v_exp_f32, ~1 ulp on 2^t): absolute error ~1e-7 on
 // outputs in [0, 1] / [-1, 1], far inside the 1e-5 parity bar, at a tenth of libm's instruction count
-// (v_rcp_f32 is within 1 ulp; `1.0f / x` would be the ten-instruction correctly rounded division, 48 times per lane and tile)
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
 #ifdef RG_ACTOR_STAMPS  // diagnostic build (tools/actor_stamps.py): wave-cycle stamps of the phases, written over q
 #define RG_ASTAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
@@ -52,29 +51,17 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 #define RG_ASTAMP(i)
 #endif
 
-// Two [TM][H] images in LDS with pitch exactly H -- 32 KB per workgroup at H = 128, so that TWO workgroups fit the 64 KB of
-// LDS per CU this runtime schedules against (round 4: with 42.5 KB -- padded pitch, a third image for the inputs -- only one
-// workgroup ran per CU, the chip did the 512 tiles of the benchmark batch in two rounds and one tile's serial phases never
-// overlapped another tile's matrix work).  Bank conflicts are avoided by an XOR swizzle of the 16-byte block index with the
-// row instead of padding: block b of row i lives at block b ^ (i & 7).  The eight lanes of an LDS lane group read the
-// same logical block of eight consecutive rows -> eight different physical blocks -> all 32 banks.
 template <int H>
-__device__ __forceinline__ int swz(int i, int k) { return i * H + ((((k >> 2) ^ (i & 7)) << 2) | (k & 3)); }
-template <int H>
-__device__ __forceinline__ int swz4(int i, int k4) { return i * H + ((k4 ^ (i & 7)) << 2); }
-
-template <int H>
-__attribute__((amdgpu_waves_per_eu(2, 2)))   // 256 registers (VGPR + AGPR): two tiles per CU, one's serial phases under the other's MFMAs
 __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
 #ifdef RG_ACTOR_STAMPS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    constexpr int NW = H / 32;  // wavefronts per tile
-    constexpr int NTHREADS = 64 * NW;
-    __shared__ __attribute__((aligned(16))) float lds[2 * TM * H];
-    float *const Y = lds;            // fc1's output (A operand of the GRU), later fc2's partial sums
-    float *const Hs = lds + TM * H;  // the old hidden state (A operand), then the new one
+    constexpr int HP = H + 4;  // LDS row pitch (floats): rows 16 B aligned, bank-staggered
+    constexpr int NTHREADS = 64 * (H / 32);
+    __shared__ __attribute__((aligned(16))) float Xs[TM][MAX_IP + 4];
+    __shared__ __attribute__((aligned(16))) float Y1[TM][HP];
+    __shared__ __attribute__((aligned(16))) float Hs[TM][HP];
     const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6, half = lane >> 5, col = lane & 31;
     const int E = a.E, N = a.N, A = a.w.n_actions, I = a.w.input_dim, IP = a.ip;
     const bool shared = a.w.n_sets == 1;
@@ -95,20 +82,30 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     const float *Whh = a.w.whh + static_cast<size_t>(set) * 3 * H * H, *Bhh = a.w.bhh + static_cast<size_t>(set) * 3 * H;
     const float *W2 = a.w.w2 + static_cast<size_t>(set) * A * H, *B2 = a.w.b2 + static_cast<size_t>(set) * A;
 
-    // ---- the old hidden state: every thread's share of the tile is requested first and lands in LDS behind fc1
-    constexpr int HV = (TM * (H / 4)) / NTHREADS;  // float4 per thread (4)
-    float4 hv[HV];
-#pragma unroll
-    for (int m = 0; m < HV; ++m) {
-        const int idx = tid + NTHREADS * m, i = idx / (H / 4), k4 = idx % (H / 4);
-        // (the loads do not wait for the restart flag: one memory round trip, the flag is applied to what comes back)
-        const bool ok = row_ok(i);
-        const int r = ok ? row_of(i) : 0;
-        hv[m] = *reinterpret_cast<const float4 *>(a.hidden + static_cast<size_t>(r) * H + 4 * k4);
-        // a restarted env starts from the reference's reset(): zero hidden state, zero observation (PredatorCapturePrey.py:136)
-        const bool keep = ok && !(a.restart && a.restart[r / N] != 0);
-        if (!keep) hv[m] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // ---- stage the input rows (observation + optional one-hot agent id), the old hidden state and fc1's weights
+    for (int idx = tid; idx < TM * IP; idx += NTHREADS) {
+        const int i = idx / IP, k = idx - i * IP;
+        float v = 0.0f;
+        if (row_ok(i)) {
+            const int r = row_of(i);
+            // a restarted env is seen through the reference's reset() observation: zeros (PredatorCapturePrey.py:136)
+            if (k < a.D) v = (a.restart && a.restart[r / N] != 0) ? 0.0f : a.obs[static_cast<size_t>(r) * a.D + k];
+            else if (a.append_agent_id && k - a.D == r % N) v = 1.0f;
+        }
+        Xs[i][k] = v;
     }
+    for (int idx = tid; idx < TM * (H / 4); idx += NTHREADS) {
+        const int i = idx / (H / 4), k4 = idx - i * (H / 4);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row_ok(i)) {
+            const int r = row_of(i);
+            const bool fresh = a.restart && a.restart[r / N] != 0;
+            if (!fresh) v = *reinterpret_cast<const float4 *>(a.hidden + static_cast<size_t>(r) * H + 4 * k4);
+        }
+        *reinterpret_cast<float4 *>(&Hs[i][4 * k4]) = v;
+    }
+    __syncthreads();
+    RG_ASTAMP(0);  // inputs staged
 
     auto zero16 = [] {
         floatx16 z;
@@ -125,45 +122,28 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     };
     auto crow = [&](int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; };  // tile row of accumulator register `reg`
 
-    // ---- fc1 + ReLU: Y = relu(X W1^T + b1); this wave's 32 columns.  The layer is small and its rows are ragged (I is not a
-    // multiple of 4): scalar operand loads straight from memory (the observation row of tile row `col` + the one-hot agent
-    // id; every wave of the tile reads the same 32 short rows: L1 hits), zero beyond I, all in flight before the first product.
+    // ---- fc1 + ReLU: Y1 = relu(X W1^T + b1); this wave's 32 columns.  The layer is small and its rows are
+    // ragged (I is not a multiple of 4): scalar operand loads, zero beyond I.
     {
         const int n = cb * 32 + col;
         floatx16 acc = zero16();
-        float w[MAX_IP / 2], xv[MAX_IP / 2];
-        const bool ok = row_ok(col);
-        const int r = ok ? row_of(col) : 0;
-        const int env = r / N, agent = r - env * N;
-        const float *xrow = a.obs + static_cast<size_t>(r) * a.D;
-#pragma unroll
-        for (int kk = 0; kk < MAX_IP / 2; ++kk) {   // (again without waiting for the restart flag)
-            const int k = half * (IP / 2) + kk;
-            xv[kk] = (kk < IP / 2 && k < a.D) ? xrow[k] : 0.0f;
-            w[kk] = (kk < IP / 2 && k < I) ? W1[n * I + k] : 0.0f;
-        }
-        const bool live = ok && !(a.restart && a.restart[env] != 0);
+        float w[MAX_IP / 2], xv[MAX_IP / 2];  // all operand loads in flight before the first product
 #pragma unroll
         for (int kk = 0; kk < MAX_IP / 2; ++kk) {
             const int k = half * (IP / 2) + kk;
             const bool in = kk < IP / 2;
-            if (in && k < a.D) xv[kk] = live ? xv[kk] : 0.0f;
-            else if (in && ok && a.append_agent_id && k - a.D == agent) xv[kk] = 1.0f;
+            w[kk] = (in && k < I) ? W1[n * I + k] : 0.0f;
+            xv[kk] = in ? Xs[col][k] : 0.0f;
         }
 #pragma unroll
         for (int kk = 0; kk < MAX_IP / 2; ++kk)
             if (kk < IP / 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[kk], w[kk], acc, 0, 0, 0);
         const float b = B1[n];
 #pragma unroll
-        for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = fmaxf(acc[r_] + b, 0.0f);
-    }
-#pragma unroll
-    for (int m = 0; m < HV; ++m) {
-        const int idx = tid + NTHREADS * m, i = idx / (H / 4), k4 = idx % (H / 4);
-        *reinterpret_cast<float4 *>(&Hs[swz4<H>(i, k4)]) = hv[m];
+        for (int r = 0; r < 16; ++r) Y1[crow(r)][n] = fmaxf(acc[r] + b, 0.0f);
     }
     __syncthreads();
-    RG_ASTAMP(1);  // fc1 done, old hidden state staged
+    RG_ASTAMP(1);  // fc1
 
     // ---- recurrent layer
     float hn[16];       // the new hidden state in accumulator layout (the old one is still an operand)
@@ -204,11 +184,11 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             for (int t = 0; t < NGROUPS; ++t) {
                 const int chunk = t / 6, g = (t % 6) >> 1, hh = t & 1;
                 if (t % 6 == 0) {  // this chunk's activations: A operands for all six products
-                    const int k40 = (half * (H / 2) + chunk * 32) >> 2;
+                    const int k0 = half * (H / 2) + chunk * 32;
 #pragma unroll
                     for (int q4 = 0; q4 < 8; ++q4) {
-                        xa[q4] = *reinterpret_cast<const float4 *>(&Y[swz4<H>(col, k40 + q4)]);
-                        ha[q4] = *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k40 + q4)]);
+                        xa[q4] = *reinterpret_cast<const float4 *>(&Y1[col][k0 + 4 * q4]);
+                        ha[q4] = *reinterpret_cast<const float4 *>(&Hs[col][k0 + 4 * q4]);
                     }
                 }
                 if (t + 1 < NGROUPS) load_line(t + 1, wnext);
@@ -232,7 +212,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 const float rg_ = sigmoidf_((gi[0][r] + bir) + (gh[0][r] + bhr));
                 const float zg = sigmoidf_((gi[1][r] + biz) + (gh[1][r] + bhz));
                 const float ng = tanhf_((gi[2][r] + bin) + rg_ * (gh[2][r] + bhn));
-                hn[r] = (1.0f - zg) * ng + zg * Hs[swz<H>(crow(r), j)];
+                hn[r] = (1.0f - zg) * ng + zg * Hs[crow(r)][j];
             }
         }
     } else {  // use_rnn = False: h = relu(Linear(x))  (rnn_agent.py:13,27); the weights sit in the wih / bih slots
@@ -241,7 +221,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             floatx16 acc = zero16();
             for (int kk = 0; kk < H / 2; kk += 4) {
                 const int k0 = half * (H / 2) + kk;
-                acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Y[swz4<H>(col, k0 >> 2)]),
+                acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Y1[col][k0]),
                             *reinterpret_cast<const float4 *>(Wih + static_cast<size_t>(j) * H + k0));
             }
             const float b = Bih[j];
@@ -254,75 +234,48 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(hn[r]));
     RG_ASTAMP(3);  // gates
 #endif
-    __syncthreads();  // every read of the old hidden state and of Y is done
+    __syncthreads();  // every read of the old hidden state is done
     {
         const int j = cb * 32 + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = crow(r);
-            Hs[swz<H>(i, j)] = hn[r];
-        }
-    }
-    __syncthreads();
-    RG_ASTAMP(4);  // new hidden state in LDS (its copy to memory goes out at the very end: a barrier would wait for the stores)
-
-    // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one 32 x 32 tile).  The K range is split over the tile's wavefronts --
-    // 32 k values = 16 MFMAs each instead of H / 2 on one wavefront while the others wait -- and the partial tiles meet in LDS.
-    {
-        floatx16 acc = zero16();
-        const bool n_ok = col < A;
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 4) {
-            const int k0 = cb * 32 + half * 16 + kk;
-            float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (n_ok) w = *reinterpret_cast<const float4 *>(W2 + static_cast<size_t>(col) * H + k0);
-            acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k0 >> 2)]), w);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Y[cb * (TM * 32) + crow(r) * 32 + col] = acc[r];  // Y is free again: NW partial tiles, row-major
-    }
-    __syncthreads();
-    RG_ASTAMP(5);  // fc2 partial products
-    {   // every thread: TPR threads per tile row, CPT action columns each; then the greedy action of the row
-        constexpr int TPR = NTHREADS / TM, CPT = 32 / TPR;
-        const int i = tid / TPR, sub = tid % TPR;
-        const bool ok = row_ok(i);
-        const int r = ok ? row_of(i) : 0;
-        float best = -3.0e38f;
-        int arg = 0x7FFFFFFF;
-#pragma unroll
-        for (int c_ = 0; c_ < CPT; ++c_) {
-            const int c = sub * CPT + c_;
-            if (c < A) {
-                float v = 0.0f;
-#pragma unroll
-                for (int wv = 0; wv < NW; ++wv) v = v + Y[wv * (TM * 32) + i * 32 + c];
-                v = v + B2[c];
-                if (ok && a.q) a.q[static_cast<size_t>(r) * A + c] = v;
-                if (v > best) {  // first maximum, like torch.argmax
-                    best = v;
-                    arg = c;
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 1; d < TPR; d <<= 1) {   // the TPR threads of a row are neighbouring lanes
-            const float ob = __shfl_xor(best, d);
-            const int oa = __shfl_xor(arg, d);
-            if (ob > best || (ob == best && oa < arg)) {
-                best = ob;
-                arg = oa;
-            }
-        }
-        if (ok && sub == 0 && a.actions) a.actions[r] = arg;
-    }
-    {
-        const int j = cb * 32 + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = crow(r);
+            Hs[i][j] = hn[r];
             if (row_ok(i)) a.hidden[static_cast<size_t>(row_of(i)) * H + j] = hn[r];
         }
+    }
+    __syncthreads();
+    RG_ASTAMP(4);  // new hidden state stored
+
+    // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one tile, wavefront 0), then the greedy action per row
+    if (cb == 0) {
+        floatx16 acc = zero16();
+        const bool n_ok = col < A;
+        for (int kk = 0; kk < H / 2; kk += 4) {
+            const int k0 = half * (H / 2) + kk;
+            float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (n_ok) w = *reinterpret_cast<const float4 *>(W2 + static_cast<size_t>(col) * H + k0);
+            acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Hs[col][k0]), w);
+        }
+        const float b = n_ok ? B2[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y1[crow(r)][col] = acc[r] + b;  // Y1 is free again: the q tile, row-major
+    }
+    __syncthreads();
+    RG_ASTAMP(5);  // fc2
+    if (tid < TM && row_ok(tid)) {
+        const int r = row_of(tid);
+        float best = Y1[tid][0];
+        int arg = 0;
+        for (int n = 0; n < A; ++n) {
+            const float v = Y1[tid][n];
+            if (a.q) a.q[static_cast<size_t>(r) * A + n] = v;
+            if (v > best) {  // first maximum, like torch.argmax
+                best = v;
+                arg = n;
+            }
+        }
+        if (a.actions) a.actions[r] = arg;
     }
 #ifdef RG_ACTOR_STAMPS
     RG_ASTAMP(6);
@@ -398,9 +351,9 @@ extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int
     if (in_dim != w->input_dim) return fail(-7, "obs_dim (+ n_agents with append_agent_id) != the actor's input_dim");
     const int ip = (in_dim + 7) / 8 * 8;
     if (ip > rg::MAX_IP) return fail(-8, "input_dim above 64 is not supported");
-    if ((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(w->w1) | reinterpret_cast<uintptr_t>(w->wih) |
-         reinterpret_cast<uintptr_t>(w->whh) | reinterpret_cast<uintptr_t>(w->w2)) & 15u)
-        return fail(-9, "hidden, w1, wih, whh and w2 must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(w->wih) | reinterpret_cast<uintptr_t>(w->whh) |
+         reinterpret_cast<uintptr_t>(w->w2)) & 15u)
+        return fail(-9, "hidden, wih, whh and w2 must be 16-byte aligned");
     rg::ActorArgs a;
     a.w = *w;
     a.obs = obs;
