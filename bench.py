@@ -29,6 +29,7 @@ ALGO_BYTES_PER_ENV_STEP = 585
 # the same for the other BASELINE configurations (Warehouse N=8, D=18; MaterialTransport N=6, D=9)
 ALGO_BYTES_OTHER = {"Warehouse": 896, "MaterialTransport": 510}
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS = 157.3, 2500.0   # dense matrix peaks (MI355X_MICROARCH.md; never the 2:1-sparsity figures)
 
 
 PMC_PROFILE = os.path.join("profiles", "r3_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
@@ -316,6 +317,50 @@ def saturated_leg(dev, overrides, E=SATURATED_ENVS):
            "hbm_achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
     env.close()
     return out
+
+
+def actor_leg(dev, E=4096, N=4, D=16, H=128, A=5, bursts=7, reps=100):
+    """Side measurement (not `value`): the fused policy-inference kernel of row f3 (csrc/actor_mfma.hip, rg_actor_forward) at
+    the evaluation loop's shape -- PredatorCapturePrey's zoo actor: 4096 envs x 4 agents, 16 observation floats + agent id,
+    GRU hidden 128, 5 actions, random weights -- with its own roofline.  flops = the network's multiply-adds x 2 (fc1 + the two
+    GRU matrices + fc2); the bound is the matrix cores: `frac` prices them against the DENSE FLOAT32 MFMA peak, although the GRU's
+    products run as six bfloat16 plane products each (float32 = three bfloat16 planes, robogym.h rg_actor_pack_gru_bf16x3):
+    `mfma_bf16_frac` is the same launch priced as the bfloat16 MFMA instructions it issues against the bfloat16 peak."""
+    import torch
+    from marbler_amd.evaluate import BatchedActor
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * 0.3  # noqa: E731
+    I = D + N
+    sd = {"fc1.weight": r(H, I), "fc1.bias": r(H), "rnn.weight_ih": r(3 * H, H), "rnn.weight_hh": r(3 * H, H), "rnn.bias_ih": r(3 * H),
+          "rnn.bias_hh": r(3 * H), "fc2.weight": r(A, H), "fc2.bias": r(A)}
+    actor = BatchedActor(sd, N, device=dev)
+    obs = torch.rand(E, N, D, device=dev)
+    hidden = torch.zeros(E, N, H, device=dev)
+    q = torch.empty(E, N, A, device=dev)
+    act = torch.empty(E, N, dtype=torch.int32, device=dev)
+    for _ in range(20):
+        actor.forward_fused(obs, hidden, q_out=q, actions_out=act)
+    torch.cuda.synchronize(dev)
+    times = []
+    for _ in range(bursts):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            actor.forward_fused(obs, hidden, q_out=q, actions_out=act)
+        b.record()
+        torch.cuda.synchronize(dev)
+        times.append(a.elapsed_time(b) / reps)
+    ms = sorted(times)[len(times) // 2]
+    flop = 2.0 * E * N * (I * H + 2 * 3 * H * H + H * A)
+    gru_bf16_flop = 6 * 2.0 * E * N * (2 * 3 * H * H)      # six plane products per float32 product, as issued
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"kernel": "rg::actor_kernel<128, split> (rg_actor_forward, GRU on three bfloat16 planes)", "rows": E * N, "hidden": H, "ms_per_launch": ms,
+            "ms_per_launch_min": min(times), "flops_per_launch": flop,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
+                         "peak_kind": "dense float32 MFMA (the reference evaluates the actor in float32); the launch issues bfloat16 MFMAs",
+                         "mfma_bf16_issued_TFLOPs": gru_bf16_flop / (ms * 1e-3) / 1e12,
+                         "mfma_bf16_frac": gru_bf16_flop / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS},
+            "agent_rows_per_s": E * N / (ms * 1e-3)}
 
 
 def launch_ranks(args):
@@ -623,6 +668,7 @@ def main():
                 out["graph_replay"] = graph_leg(env, dev, ptrs, min(K, 100))
             out["rollout"] = rollout_leg(env, dev, n_act, 777)
             out["saturated"] = saturated_leg(dev, overrides)
+            out["actor"] = actor_leg(dev)
             out["saturated_2m"] = saturated_leg(dev, overrides, 4 * SATURATED_ENVS)
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref

@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-/* 4 (round 3): + rg_step_kernel(); rg_bind_state now invalidates the drawn-ahead blocks itself.  Structs unchanged since 3. */
-#define RG_ABI_VERSION 4
+/* 5 (round 4): + rg_actor_pack_gru_bf16x3() and rg_actor_weights.gru_packed == 2; rg_rollout takes every shape (no E*N*D % 4
+ * rule); the one-lane-per-env step kernel covers N <= 6.  Structs unchanged since 3. */
+#define RG_ABI_VERSION 5
 #define RG_MAX_AGENTS 16
 #define RG_MAX_PREY 64
 
@@ -236,7 +237,8 @@ typedef struct {
     const float *whh, *bhh; /* [S][3H][H], [S][3H] */
     const float *w2, *b2;   /* [S][A][H], [S][A] */
     int32_t n_sets, input_dim, hidden_dim, n_actions, use_rnn;
-    int32_t gru_packed;     /* wih / whh hold the streaming order written by rg_actor_pack_gru */
+    int32_t gru_packed;     /* 0: wih / whh in torch's layout; 1: the float32 streaming order written by rg_actor_pack_gru;
+                               2: three bfloat16 planes written by rg_actor_pack_gru_bf16x3 (6 bytes per weight) */
 } rg_actor_weights;
 
 /* One actor step (misc.py:160-170: `actor(obs, hs)` then arg-max).  obs [E][N][D]; with
@@ -252,6 +254,13 @@ int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agen
  * kernel streams it (1 KB per load instruction instead of 64 scattered 16-byte pieces).  dst: a device
  * buffer of the same size; use it as wih / whh with gru_packed = 1. */
 int rg_actor_pack_gru(const float *src, int32_t n_sets, int32_t hidden_dim, float *dst, void *hip_stream);
+/* The same matrix as three bfloat16 planes -- w = hi + mid + lo exactly up to 2^-24 |w|, each plane the top 16 bits of what
+ * the planes before it leave -- in the order the kernel streams them.  dst: 6 bytes per weight = 3/2 of the size of src,
+ * 16-byte aligned; use it as wih / whh with gru_packed = 2.  The GRU's products then run on the bfloat16 matrix cores (16 x
+ * the float32 MFMA rate) as six plane products per float32 product, the hidden state and fc1's output being split the same
+ * way on the fly; the three products of order 2^-24 are left out, which keeps the error below the rounding error of a
+ * float32 dot product of the same length (rnn_agent.py:24 `self.rnn(x, h_in)` evaluated in float32 is the reference). */
+int rg_actor_pack_gru_bf16x3(const float *src, int32_t n_sets, int32_t hidden_dim, void *dst, void *hip_stream);
 const char *rg_actor_last_error(void);
 
 #ifdef __cplusplus

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 MAX_AGENTS, MAX_PREY = 16, 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 RESET_BOOK_EPISODE = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -81,7 +81,7 @@ class RgActorWeights(C.Structure):
 
 EXPORTS = ("rg_abi_version", "rg_last_error", "rg_sizeof_params", "rg_sizeof_state", "rg_sizeof_step_io", "rg_next_init_stride",
            "rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs", "rg_step_kernel",
-           "rg_actor_forward", "rg_actor_pack_gru", "rg_actor_last_error")
+           "rg_actor_forward", "rg_actor_pack_gru", "rg_actor_pack_gru_bf16x3", "rg_actor_last_error")
 
 _lib = None
 
@@ -123,6 +123,8 @@ def load():
     lib.rg_actor_forward.restype = C.c_int
     lib.rg_actor_pack_gru.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_actor_pack_gru.restype = C.c_int
+    lib.rg_actor_pack_gru_bf16x3.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rg_actor_pack_gru_bf16x3.restype = C.c_int
     lib.rg_actor_last_error.restype = C.c_char_p
     for f in (lib.rg_destroy, lib.rg_bind_state, lib.rg_set_stream, lib.rg_reset, lib.rg_step, lib.rg_rollout, lib.rg_get_obs,
               lib.rg_sizeof_params, lib.rg_sizeof_state, lib.rg_sizeof_step_io):

@@ -2,21 +2,27 @@
 // fc2, or rnn_ns_agent.py:5-36 with one such network per agent) for all E x N agents of a batch in
 // ONE launch: policy inference for on-device evaluation rollouts.
 //
-// This is the one dense contraction on the path, so it runs on the matrix cores: f32-input MFMA
-// (v_mfma_f32_32x32x2_f32, exact f32 products and sums -- the parity bar against the reference's
-// float32 modules is 1e-5, which rules the 16x faster bf16 forms out).  One workgroup of H/32
-// wavefronts owns a tile of 32 agent rows and carries it through the whole network, wavefront w
-// computing the 32 hidden columns [32 w, 32 w + 32) of every layer:
-//     X [32 x I]  --fc1-->  Y1 [32 x H]  --GRU (6 gate tiles per 32 hidden columns)-->  h' [32 x H]  --fc2--> q [32 x A]
-// A operands (activations) are read from LDS as float4 = four k-steps; B operands (weights) stream
-// from L2 as float4 per lane (each weight matrix is read once per tile; all tiles share it in L2; fc1's
-// small ragged matrix is staged in LDS, padded).  The k index of lane half h runs over
-// [h K/2, (h+1) K/2): any pairing of k values into MFMA steps gives the same sum up to rounding, and
-// this one makes both operands contiguous.  Layer outputs come out of the MFMA with the column on the
-// lane and 16 rows in registers (C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
-// the gate arithmetic is elementwise in that layout, and one LDS write turns it into the next layer's
-// row-major A image.  Non-shared actors: a tile takes the rows of ONE agent index (stride N), so the
-// whole tile uses one weight set.
+// This is the one dense contraction on the path, so it runs on the matrix cores.  One workgroup of H/32 wavefronts owns a
+// tile of 32 agent rows and carries it through the whole network, wavefront w computing the 32 hidden columns
+// [32 w, 32 w + 32) of every layer:
+//     X [32 x I]  --fc1-->  Y [32 x H]  --GRU (6 gate tiles per 32 hidden columns)-->  h' [32 x H]  --fc2--> q [32 x A]
+// * The GRU -- 96 % of the arithmetic -- has two forms.  gru_packed == 2 (rg_actor_pack_gru_bf16x3, the default of
+//   marbler_amd/evaluate.py): every float32 value is carried as THREE bfloat16 planes (see split8 below) and a float32
+//   product becomes six plane products on v_mfma_f32_32x32x16_bf16 (32 cycles for K = 16), 6/16 of the float32 MFMA time, with
+//   an error below a float32 dot product's own roundings.  gru_packed == 0 / 1: f32-input MFMA (v_mfma_f32_32x32x2_f32, 64
+//   cycles for K = 2), exact float32 products.  Round 4 at 4096 x 4 rows, hidden 128: 27.8 us per launch against 47-50 us
+//   (119.8 TFLOP/s of the network's arithmetic = 76 % of the dense float32 MFMA peak; 8192 x 4: 86 %).
+// * A operands (activations) are read from LDS as float4 blocks; B operands (weights) stream from L2 in the order a pack routine
+//   wrote them (1 KB per load instruction).  fc1's small ragged matrix and the observation rows are read as they lie, by a
+//   ROLLED loop (the layer unrolled was ~600 instructions of cold code at the head of every launch: the instruction fetch made
+//   the first operands arrive 13-15 k cycles into the wave).
+// * Two [32][H] LDS images with an XOR swizzle instead of padding: 32 KB per tile, TWO tiles per CU (the runtime schedules
+//   against 64 KB of LDS per CU; the padded 42.5 KB of rounds 1-3 let one tile run per CU, two rounds for the benchmark batch).
+// * Layer outputs come out of the MFMA with the column on the lane and 16 rows in registers (C/D map: col = lane & 31,
+//   row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); the gate arithmetic is elementwise in that layout and one LDS write turns it
+//   into the next layer's A image.  fc2's K range is split over the tile's wavefronts, the partial tiles meet in LDS, and all
+//   threads take part in the bias / arg-max / q stores.  Non-shared actors: a tile takes the rows of ONE agent index (stride N),
+//   so the whole tile uses one weight set.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -26,6 +32,40 @@
 namespace rg {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- float32 carried as three bfloat16 planes (gru_packed == 2; round 4).
+// v_mfma_f32_32x32x2_f32 costs 64 cycles for K = 2; v_mfma_f32_32x32x16_bf16 costs 32 cycles for K = 16: 16 x the rate.  A
+// float32 value is EXACTLY hi + mid + lo with hi = the top 16 bits of x (a bfloat16 by truncation), mid = the top 16 bits of
+// x - hi, lo = the top 16 bits of x - hi - mid (what is dropped is below 2^-24 |x|).  A product x w is then the sum of nine
+// plane products, of which the six of order >= 2^-16 are computed -- hh, hm, mh, hl, lh, mm, each exact in the MFMA's float32
+// accumulator -- and the three of order 2^-24 are left out: 6 / 16 of the float32 MFMA time for an error BELOW that of a
+// float32 dot product's own roundings (measured on 4096 x 128 x 384 random operands: 3.6e-7 against the exact product, a
+// float32 GEMM 2.5e-6).  Same exponent range as float32: nothing can overflow or flush that float32 would not.
+// split8: eight consecutive k values of one row -> the three planes as MFMA operands (element e of a plane = k0 + e)
+__device__ __forceinline__ void split8(const float4 &lo4, const float4 &hi4, bf16x8 &ph, bf16x8 &pm, bf16x8 &pl) {
+    const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    uint32_t bh[8], bm[8], bl[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bh[e] = __builtin_bit_cast(uint32_t, x[e]) & 0xFFFF0000u;
+        const float r1 = x[e] - __builtin_bit_cast(float, bh[e]);   // exact
+        bm[e] = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, bm[e]);     // exact
+        bl[e] = __builtin_bit_cast(uint32_t, r2);                    // (truncated by the packing below)
+    }
+    u32x4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // two bfloat16 per register: element 2q in the low half
+        h[q] = __builtin_amdgcn_perm(bh[2 * q + 1], bh[2 * q], 0x07060302u);
+        m[q] = __builtin_amdgcn_perm(bm[2 * q + 1], bm[2 * q], 0x07060302u);
+        l[q] = __builtin_amdgcn_perm(bl[2 * q + 1], bl[2 * q], 0x07060302u);
+    }
+    ph = __builtin_bit_cast(bf16x8, h);
+    pm = __builtin_bit_cast(bf16x8, m);
+    pl = __builtin_bit_cast(bf16x8, l);
+}
 
 constexpr int TM = 32;        // agent rows per wavefront
 constexpr int MAX_IP = 64;    // padded input width (multiple of 8)
@@ -63,7 +103,7 @@ __device__ __forceinline__ int swz(int i, int k) { return i * H + ((((k >> 2) ^ 
 template <int H>
 __device__ __forceinline__ int swz4(int i, int k4) { return i * H + ((k4 ^ (i & 7)) << 2); }
 
-template <int H>
+template <int H, bool SPLIT>   // SPLIT: the GRU's products on bfloat16 planes (gru_packed == 2)
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256 registers (VGPR + AGPR): two tiles per CU, one's serial phases under the other's MFMAs
 __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
 #ifdef RG_ACTOR_STAMPS
@@ -131,29 +171,38 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     {
         const int n = cb * 32 + col;
         floatx16 acc = zero16();
-        float w[MAX_IP / 2], xv[MAX_IP / 2];
         const bool ok = row_ok(col);
         const int r = ok ? row_of(col) : 0;
         const int env = r / N, agent = r - env * N;
         const float *xrow = a.obs + static_cast<size_t>(r) * a.D;
-#pragma unroll
-        for (int kk = 0; kk < MAX_IP / 2; ++kk) {   // (again without waiting for the restart flag)
-            const int k = half * (IP / 2) + kk;
-            xv[kk] = (kk < IP / 2 && k < a.D) ? xrow[k] : 0.0f;
-            w[kk] = (kk < IP / 2 && k < I) ? W1[n * I + k] : 0.0f;
-        }
+        const float *wrow = W1 + static_cast<size_t>(n) * I;
         const bool live = ok && !(a.restart && a.restart[env] != 0);
+        const int id_k = (ok && a.append_agent_id) ? a.D + agent : -1;   // where this row's one-hot agent id sits
+        // A ROLLED loop, four k-steps per trip: unrolled over the widest input (32 steps, two predicated loads each) the layer was
+        // ~600 instructions of straight-line code that every CU fetches cold at the start of every launch -- the instruction
+        // fetch, not the data, made the first operands arrive 13-15 k cycles into a 52 k-cycle wave (round 4, -DRG_ACTOR_STAMPS_FC1)
+        const int steps = IP / 2;   // per lane half; IP is a multiple of 8
+#pragma unroll 1
+        for (int kk0 = 0; kk0 < steps; kk0 += 4) {
+            float xq[4], wq[4];
 #pragma unroll
-        for (int kk = 0; kk < MAX_IP / 2; ++kk) {
-            const int k = half * (IP / 2) + kk;
-            const bool in = kk < IP / 2;
-            if (in && k < a.D) xv[kk] = live ? xv[kk] : 0.0f;
-            else if (in && ok && a.append_agent_id && k - a.D == agent) xv[kk] = 1.0f;
+            for (int c = 0; c < 4; ++c) {
+                const int k = half * steps + kk0 + c;
+                xq[c] = k < a.D ? xrow[k] : 0.0f;        // (k < D: inside the row; the select below applies the restart flag)
+                wq[c] = k < I ? wrow[k] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = half * steps + kk0 + c;
+                const float x = k < a.D ? (live ? xq[c] : 0.0f) : (k == id_k ? 1.0f : 0.0f);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, wq[c], acc, 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int kk = 0; kk < MAX_IP / 2; ++kk)
-            if (kk < IP / 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[kk], w[kk], acc, 0, 0, 0);
         const float b = B1[n];
+#ifdef RG_ACTOR_STAMPS_FC1
+        asm volatile("" ::"v"(acc), "v"(b));
+        RG_ASTAMP(3);
+#endif
 #pragma unroll
         for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = fmaxf(acc[r_] + b, 0.0f);
     }
@@ -176,6 +225,48 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 gi[g] = zero16();
                 gh[g] = zero16();
             }
+            if constexpr (SPLIT) {
+                // K in steps of 16: lane (col, half) holds k = 16 ks + 8 half + e, e = 0..7, of its row (activations: tile row
+                // `col`; weights: gate row g H + j) -- three 16-byte operands per matrix and step, written in exactly this
+                // order by rg_actor_pack_gru_bf16x3: [cb][ks][gate][plane][lane][8].  Groups (ks, gate, matrix) are
+                // software-pipelined two deep: 2 x 6 MFMAs = 384 cycles cover the weight loads' trip to L2.
+                constexpr int KS = H / 16, NG = KS * 6;
+                // (6 bytes per weight: a set's planes are 3/2 the size of its float32 matrix)
+                const size_t set_off = static_cast<size_t>(set) * 3 * H * H * 3;
+                const uint16_t *Pih = reinterpret_cast<const uint16_t *>(a.w.wih) + set_off, *Phh = reinterpret_cast<const uint16_t *>(a.w.whh) + set_off;
+                auto load_w = [&](int t, u32x4 (&wl)[3]) {
+                    const int ks = t / 6, g = (t % 6) >> 1, hh = t & 1;
+                    const uint16_t *src = (hh ? Phh : Pih) + ((static_cast<size_t>((cb * KS + ks) * 3 + g) * 3) * 64 + lane) * 8;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wl[pl] = *reinterpret_cast<const u32x4 *>(src + pl * 64 * 8);
+                };
+                u32x4 wq[3][3];
+                load_w(0, wq[0]);
+                load_w(1, wq[1]);
+                bf16x8 yh, ym, yl, hh_, hm_, hl_;
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    const int ks = t / 6, g = (t % 6) >> 1, hh = t & 1;
+                    if (t % 6 == 0) {   // this step's activations, split once for all six products
+                        const int k4 = 4 * ks + 2 * half;
+                        split8(*reinterpret_cast<const float4 *>(&Y[swz4<H>(col, k4)]), *reinterpret_cast<const float4 *>(&Y[swz4<H>(col, k4 + 1)]), yh, ym, yl);
+                        split8(*reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k4)]), *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k4 + 1)]), hh_, hm_, hl_);
+                    }
+                    if (t + 2 < NG) load_w(t + 2, wq[(t + 2) % 3]);
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[t % 3][0]), wm = __builtin_bit_cast(bf16x8, wq[t % 3][1]),
+                                 wl = __builtin_bit_cast(bf16x8, wq[t % 3][2]);
+                    const bf16x8 xh = hh ? hh_ : yh, xm = hh ? hm_ : ym, xl = hh ? hl_ : yl;
+                    floatx16 acc = hh ? gh[g] : gi[g];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wm, acc, 0, 0, 0);   // small terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc, 0, 0, 0);
+                    if (hh) gh[g] = acc;
+                    else gi[g] = acc;
+                }
+            } else {
             // The weight stream: lane (col, half) owns row g H + j of each gate matrix and, of that row, the
             // k range of its half -- consumed in chunks of 32 floats = one 128-byte line per lane, eight
             // float4 loads issued together, so a line is used up while it is hot (with 16 B per visit the
@@ -220,6 +311,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) wcur[q4] = wnext[q4];
             }
+            }  // !SPLIT
 #ifdef RG_ACTOR_STAMPS
 #pragma unroll
             for (int g = 0; g < 3; ++g) asm volatile("" ::"v"(gi[g]), "v"(gh[g]));
@@ -252,7 +344,9 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #ifdef RG_ACTOR_STAMPS
 #pragma unroll
     for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(hn[r]));
+#ifndef RG_ACTOR_STAMPS_FC1
     RG_ASTAMP(3);  // gates
+#endif
 #endif
     __syncthreads();  // every read of the old hidden state and of Y is done
     {
@@ -264,7 +358,10 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         }
     }
     __syncthreads();
-    RG_ASTAMP(4);  // new hidden state in LDS (its copy to memory goes out at the very end: a barrier would wait for the stores)
+#ifndef RG_ACTOR_STAMPS_FC1
+    RG_ASTAMP(4);  // new hidden state in LDS
+#endif
+    // (the new hidden state's copy to memory goes out at the very end: a barrier here would wait for the stores)
 
     // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one 32 x 32 tile).  The K range is split over the tile's wavefronts --
     // 32 k values = 16 MFMAs each instead of H / 2 on one wavefront while the others wait -- and the partial tiles meet in LDS.
@@ -327,6 +424,8 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #ifdef RG_ACTOR_STAMPS
     RG_ASTAMP(6);
     stamps[7] = static_cast<int>(t_start & 0x7FFFFFFF);   // absolute start (low bits): which waves ran side by side
+    // slot 0: where the wave ran -- XCC_ID (hwreg 20) << 16 | HW_ID (hwreg 4: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+    stamps[0] = static_cast<int>((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 16) | (__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xFFFF));
     __syncthreads();
     if (lane == 0 && a.q) {
         int *dst = reinterpret_cast<int *>(a.q) + static_cast<size_t>(E) * N * A + (static_cast<size_t>(blockIdx.x) * (H / 32) + cb) * 8;  // behind the q block
@@ -355,9 +454,52 @@ __global__ void pack_gru_kernel(const float *src, float *dst, int n_sets, int H)
     }
 }
 
+// torch layout [S][3H][H] float32 -> three bfloat16 planes in the SPLIT kernel's streaming order
+// [S][cb][ks][gate][plane][lane = (half, col)][8]: 6 bytes per weight
+__global__ void pack_gru_bf16x3_kernel(const float *src, uint16_t *dst, int n_sets, int H) {
+    const int nks = H / 16, ncb = H / 32;
+    const size_t total = static_cast<size_t>(n_sets) * 3 * H * H;   // (set, cb, ks, gate, lane, e) tuples = weights
+    for (size_t o = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        size_t r = o;
+        const int e = r % 8; r /= 8;
+        const int lane = r % 64; r /= 64;
+        const int g = r % 3; r /= 3;
+        const int ks = r % nks; r /= nks;
+        const int cb = r % ncb; r /= ncb;
+        const int s = static_cast<int>(r);
+        const int half = lane >> 5, col = lane & 31;
+        const int row = g * H + cb * 32 + col, k = ks * 16 + half * 8 + e;
+        const float w = src[(static_cast<size_t>(s) * 3 * H + row) * H + k];
+        const uint32_t bh = __builtin_bit_cast(uint32_t, w) & 0xFFFF0000u;
+        const float r1 = w - __builtin_bit_cast(float, bh);
+        const uint32_t bm = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, bm);
+        const uint32_t bl = __builtin_bit_cast(uint32_t, r2);
+        const size_t base = ((((static_cast<size_t>(s) * ncb + cb) * nks + ks) * 3 + g) * 3) * 64 * 8 + static_cast<size_t>(lane) * 8 + e;
+        dst[base] = static_cast<uint16_t>(bh >> 16);
+        dst[base + 64 * 8] = static_cast<uint16_t>(bm >> 16);
+        dst[base + 2 * 64 * 8] = static_cast<uint16_t>(bl >> 16);
+    }
+}
+
 }  // namespace rg
 
 static thread_local char g_actor_err[256] = "";
+
+extern "C" int rg_actor_pack_gru_bf16x3(const float *src, int32_t n_sets, int32_t hidden_dim, void *dst, void *hip_stream) {
+    if (!src || !dst || n_sets < 1 || (hidden_dim != 64 && hidden_dim != 128)) {
+        snprintf(g_actor_err, sizeof(g_actor_err), "rg_actor_pack_gru_bf16x3: NULL array, n_sets < 1 or hidden_dim not 64 / 128");
+        return -1;
+    }
+    if (reinterpret_cast<uintptr_t>(dst) & 15u) {
+        snprintf(g_actor_err, sizeof(g_actor_err), "rg_actor_pack_gru_bf16x3: dst must be 16-byte aligned");
+        return -9;
+    }
+    hipLaunchKernelGGL(rg::pack_gru_bf16x3_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), src,
+                       static_cast<uint16_t *>(dst), n_sets, hidden_dim);
+    return hipGetLastError() == hipSuccess ? 0 : -30;
+}
 
 extern "C" int rg_actor_pack_gru(const float *src, int32_t n_sets, int32_t hidden_dim, float *dst, void *hip_stream) {
     if (!src || !dst || n_sets < 1 || (hidden_dim != 64 && hidden_dim != 128)) {
@@ -374,8 +516,8 @@ extern "C" const char *rg_actor_last_error(void) { return g_actor_err; }
 #ifdef RG_ACTOR_STAMPS  // diagnostic build: what the runtime says about co-resident workgroups per CU
 extern "C" int rg_actor_occupancy(int hidden_dim) {
     int n = -1;
-    if (hidden_dim == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<64>, 128, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<128>, 256, 0);
+    if (hidden_dim == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<64, true>, 128, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<128, true>, 256, 0);
     return n;
 }
 #endif
@@ -392,6 +534,7 @@ extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int
     if (w->use_rnn && (!w->whh || !w->bhh)) return fail(-2, "GRU weights whh / bhh are NULL");
     if (w->hidden_dim != 64 && w->hidden_dim != 128) return fail(-3, "hidden_dim must be 64 or 128 (the reference's actors)");
     if (w->n_actions < 1 || w->n_actions > 32) return fail(-4, "n_actions must be in 1..32");
+    if (w->gru_packed < 0 || w->gru_packed > 2) return fail(-10, "gru_packed must be 0 (torch layout), 1 (rg_actor_pack_gru) or 2 (rg_actor_pack_gru_bf16x3)");
     if (w->n_sets != 1 && w->n_sets != n_agents) return fail(-5, "n_sets must be 1 (shared) or n_agents");
     if (num_envs < 1 || n_agents < 1 || obs_dim < 1) return fail(-6, "num_envs, n_agents, obs_dim must be >= 1");
     const int in_dim = obs_dim + (append_agent_id ? n_agents : 0);
@@ -416,8 +559,14 @@ extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int
     const int tiles = w->n_sets == 1 ? (num_envs * n_agents + rg::TM - 1) / rg::TM
                                      : n_agents * ((num_envs + rg::TM - 1) / rg::TM);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (w->hidden_dim == 64) hipLaunchKernelGGL((rg::actor_kernel<64>), dim3(tiles), dim3(128), 0, stream, a);
-    else hipLaunchKernelGGL((rg::actor_kernel<128>), dim3(tiles), dim3(256), 0, stream, a);
+    const bool split = w->use_rnn && w->gru_packed == 2;
+    if (w->hidden_dim == 64) {
+        if (split) hipLaunchKernelGGL((rg::actor_kernel<64, true>), dim3(tiles), dim3(128), 0, stream, a);
+        else hipLaunchKernelGGL((rg::actor_kernel<64, false>), dim3(tiles), dim3(128), 0, stream, a);
+    } else {
+        if (split) hipLaunchKernelGGL((rg::actor_kernel<128, true>), dim3(tiles), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((rg::actor_kernel<128, false>), dim3(tiles), dim3(256), 0, stream, a);
+    }
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(-30, hipGetErrorString(err));
     return 0;

@@ -23,7 +23,12 @@ class BatchedActor(object):
         self.non_shared = keys[0].startswith("agents.")
         self.use_rnn = bool(use_rnn)
         self.n_agents = int(n_agents)
-        self.pack_gru = bool(pack_gru)   # fused kernel: reorder the GRU matrices once into its streaming order
+        # fused kernel: how the two GRU matrices are handed over -- True / "bf16x3": three bfloat16 planes (the bfloat16 matrix cores,
+        # six plane products per float32 product, error below a float32 GEMM's own); "f32": float32 in the kernel's streaming order
+        # (f32-input MFMA, 16 x slower per product); False: torch's layout as it is (f32-input MFMA)
+        self.pack_gru = {True: "bf16x3", False: None, None: None}.get(pack_gru, pack_gru)
+        if self.pack_gru not in (None, "bf16x3", "f32"):
+            raise ValueError("pack_gru must be True / 'bf16x3', 'f32' or False")
 
         def stack(name):
             if self.non_shared:
@@ -78,14 +83,19 @@ class BatchedActor(object):
             if self.use_rnn:
                 t.update({k: getattr(self, k).contiguous() for k in ("wih", "bih", "whh", "bhh")})
             if self.use_rnn and self.pack_gru:
-                lib = _lib.load()   # reorder the two GRU matrices once into the kernel's streaming order
+                lib = _lib.load()   # the two GRU matrices once into the kernel's streaming order
                 stream = C.c_void_p(torch.cuda.current_stream(self.w1.device).cuda_stream)
                 for k in ("wih", "whh"):
-                    dst = torch.empty_like(t[k])
-                    if lib.rg_actor_pack_gru(t[k].data_ptr(), self.w1.shape[0], self.hidden_dim, dst.data_ptr(), stream) != 0:
+                    if self.pack_gru == "bf16x3":
+                        dst = torch.empty(t[k].numel() * 3, dtype=torch.int16, device=t[k].device)   # 6 bytes per weight
+                        rc = lib.rg_actor_pack_gru_bf16x3(t[k].data_ptr(), self.w1.shape[0], self.hidden_dim, dst.data_ptr(), stream)
+                    else:
+                        dst = torch.empty_like(t[k])
+                        rc = lib.rg_actor_pack_gru(t[k].data_ptr(), self.w1.shape[0], self.hidden_dim, dst.data_ptr(), stream)
+                    if rc != 0:
                         raise _lib.RobogymError("rg_actor_pack_gru: " + lib.rg_actor_last_error().decode())
                     t[k] = dst
-                packed = 1
+                packed = 2 if self.pack_gru == "bf16x3" else 1
             if not self.use_rnn:
                 t.update({"wih": self.wr.contiguous(), "bih": self.br.contiguous()})
             ptr = lambda k: t[k].data_ptr() if k in t else None  # noqa: E731

@@ -30,7 +30,9 @@ def _random_actor(n_sets, I, H, A, use_rnn, seed):
 
 @pytest.mark.parametrize("shared,H,E,N,D,A,use_rnn,append", [
     (True, 128, 300, 5, 16, 5, True, True),      # the PredatorCapturePrey model zoo shape (qmix.json)
-    (True, 128, 70, 5, 16, 5, True, None),       # the same on torch-layout GRU weights (no rg_actor_pack_gru)
+    (True, 128, 70, 5, 16, 5, True, None),       # the same on torch-layout GRU weights (no packing: f32-input MFMA)
+    (True, 128, 70, 5, 16, 5, True, "f32"),      # ... and on the float32 streaming order of rg_actor_pack_gru (f32-input MFMA)
+    (False, 128, 40, 4, 30, 5, True, "f32"),
     (True, 64, 77, 4, 9, 20, True, True),        # MaterialTransport: 20 actions
     (False, 64, 130, 5, 16, 5, True, False),     # rnn_ns: one network per agent, no agent id
     (True, 128, 33, 8, 18, 5, False, True),      # use_rnn = False
@@ -39,8 +41,8 @@ def _random_actor(n_sets, I, H, A, use_rnn, seed):
 def test_fused_actor_matches_torch(shared, H, E, N, D, A, use_rnn, append):
     from marbler_amd.evaluate import BatchedActor
     dev = "cuda:0"
-    pack = append is not None
-    append = True if append is None else append
+    pack = {None: False, "f32": "f32"}.get(append, True)     # True: the default, three bfloat16 planes (rg_actor_pack_gru_bf16x3)
+    append = True if append in (None, "f32") else append
     I = D + (N if append else 0)
     sd = _random_actor(1 if shared else N, I, H, A, use_rnn, seed=H + E)
     actor = BatchedActor(sd, N, use_rnn=use_rnn, device=dev, pack_gru=pack)

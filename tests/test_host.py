@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     names = _declared_functions()
     assert {"rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs",
-            "rg_actor_forward", "rg_actor_pack_gru", "rg_abi_version",
+            "rg_actor_forward", "rg_actor_pack_gru", "rg_actor_pack_gru_bf16x3", "rg_abi_version",
             "rg_last_error"} <= set(names)
     for n in names:
         assert hasattr(lib, n), n

@@ -44,14 +44,19 @@ def bind(path):
     lib.rg_actor_forward.restype = C.c_int
     lib.rg_actor_pack_gru.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_actor_pack_gru.restype = C.c_int
+    if hasattr(lib, "rg_actor_pack_gru_bf16x3"):
+        lib.rg_actor_pack_gru_bf16x3.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        lib.rg_actor_pack_gru_bf16x3.restype = C.c_int
     lib.rg_actor_last_error.restype = C.c_char_p
     return lib
 
 
-def case(lib, E, N, D, H, A, shared=True, use_rnn=True, reps=100, check=True):
+def case(lib, E, N, D, H, A, shared=True, use_rnn=True, reps=100, check=True, pack=True):
     dev = "cuda:0"
     I = D + N
-    actor = BatchedActor(_random_actor(1 if shared else N, I, H, A, use_rnn, 3), N, use_rnn=use_rnn, device=dev)
+    if pack is True and not hasattr(lib, "rg_actor_pack_gru_bf16x3"):
+        pack = "f32"
+    actor = BatchedActor(_random_actor(1 if shared else N, I, H, A, use_rnn, 3), N, use_rnn=use_rnn, device=dev, pack_gru=pack)
     _lib._lib = lib            # BatchedActor.forward_fused / _weights_struct go through marbler_amd._lib.load()
     actor._ws = None
     g = torch.Generator(device=dev).manual_seed(1)
@@ -86,7 +91,7 @@ def case(lib, E, N, D, H, A, shared=True, use_rnn=True, reps=100, check=True):
         times.append(a.elapsed_time(b) * 1e3 / reps)
     us = min(times)
     flop = 2.0 * E * N * (I * H + (2 * 3 * H * H if use_rnn else H * H) + H * A)
-    return {"E": E, "N": N, "H": H, "A": A, "shared": shared, "use_rnn": use_rnn, "us": round(us, 2), "us_median": round(sorted(times)[len(times) // 2], 2), "tflops": round(flop / us / 1e6, 1),
+    return {"pack": str(pack), "E": E, "N": N, "H": H, "A": A, "shared": shared, "use_rnn": use_rnn, "us": round(us, 2), "us_median": round(sorted(times)[len(times) // 2], 2), "tflops": round(flop / us / 1e6, 1),
             "frac_f32_mfma_peak": round(flop / us / 1e6 / 157.3, 3), "err": err}
 
 
@@ -99,8 +104,9 @@ if __name__ == "__main__":
         for (E, N, D, H, A, shared, rnn) in ((4096, 4, 16, 128, 5, True, True), (4096, 4, 16, 64, 5, True, True), (1024, 4, 16, 128, 5, True, True),
                                              (8192, 4, 16, 128, 5, True, True), (4096, 5, 16, 128, 5, False, True), (4096, 4, 9, 128, 20, True, False),
                                              (300, 5, 16, 128, 5, True, True)):
-            rows.append(case(lib, E, N, D, H, A, shared, rnn))
-            print(name, json.dumps(rows[-1]), flush=True)
+            for pack in ((True, "f32") if (hasattr(lib, "rg_actor_pack_gru_bf16x3") and rnn) else (True,)):
+                rows.append(case(lib, E, N, D, H, A, shared, rnn, pack=pack))
+                print(name, json.dumps(rows[-1]), flush=True)
         if hasattr(lib, "rg_actor_occupancy"):
             print(name, "workgroups per CU (runtime):", lib.rg_actor_occupancy(128), lib.rg_actor_occupancy(64), flush=True)
         out[name] = rows

@@ -20,6 +20,8 @@ lib.rg_actor_forward.argtypes = [ctypes.POINTER(_lib.RgActorWeights), ctypes.c_i
                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.rg_actor_pack_gru.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
 lib.rg_actor_last_error.restype = ctypes.c_char_p
+if hasattr(lib, "rg_actor_pack_gru_bf16x3"):
+    lib.rg_actor_pack_gru_bf16x3.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
 _lib._lib = lib     # the actor-only diagnostic build stands in for the library
 print(LIB)
 N, D = 4, 16
@@ -33,19 +35,21 @@ for E, H in ((4096, 128), (4096, 64), (1024, 128)):
         actor.forward_fused(obs, hidden, q_out=q)
     torch.cuda.synchronize()
     st = q.view(torch.int32).flatten()[E * N * 5:E * N * 5 + waves * 8].cpu().numpy().reshape(waves, 8)[:, :7].astype(np.float64)
-    start = q.view(torch.int32).flatten()[E * N * 5:E * N * 5 + waves * 8].cpu().numpy().reshape(waves, 8)[:, 7].astype(np.int64)
-    start = (start - start.min()) & 0x7FFFFFFF
-    print(f"hipOccupancyMaxActiveBlocksPerMultiprocessor: {lib.rg_actor_occupancy(H)} workgroups per CU; wave start times (ticks after the first): "
-          f"median {np.median(start):.0f}, 75 % {np.percentile(start, 75):.0f}, max {start.max()}; started within 5 k ticks: {(start < 5000).mean():.2f}")
+    st[:, 0] = 0
+    print(f"hipOccupancyMaxActiveBlocksPerMultiprocessor: {lib.rg_actor_occupancy(H)} workgroups per CU")
     raw = q.view(torch.int32).flatten()[E * N * 5:E * N * 5 + waves * 8].cpu().numpy().reshape(waves, 8).astype(np.int64)
     wpt = H // 32
-    xcd = (np.arange(waves) // wpt) % 8                     # workgroup b runs on XCD b % 8; every XCD has its own counter
-    spans = []
-    for x in range(8):
-        s0 = raw[xcd == x, 7]
-        s0 = (s0 - s0.min()) & 0x7FFFFFFF
-        spans.append(int((s0 + raw[xcd == x, 6]).max()))
-        late = float((s0 > 5000).mean())
+    xcc, hwid = raw[:, 0] >> 16, raw[:, 0] & 0xFFFF
+    cu = (hwid >> 8) & 0xFF            # CU + SH + SE bits: one id per CU of an XCC
+    life = raw[:, 6]
+    rel = np.zeros(waves)
+    for x in np.unique(xcc):
+        m = xcc == x
+        rel[m] = raw[m, 7] - raw[m, 7].min()
+    print(f"XCCs seen: {sorted(set(int(v) for v in xcc))}; CUs per XCC used: {np.mean([len(np.unique(cu[xcc == x])) for x in np.unique(xcc)]):.1f}; "
+          f"waves per (XCC, CU): {waves / max(1, len(set(zip(xcc.tolist(), cu.tolist())))):.2f}")
+    print(f"wave start after the XCC's first wave (ticks): median {np.median(rel):.0f}, 90 % {np.percentile(rel, 90):.0f}, max {rel.max():.0f}; "
+          f"wave end (start + life): median {np.median(rel + life):.0f}, max {(rel + life).max():.0f}; life mean {life.mean():.0f}")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(50):
@@ -53,10 +57,14 @@ for E, H in ((4096, 128), (4096, 64), (1024, 128)):
     ev1.record()
     torch.cuda.synchronize()
     us = ev0.elapsed_time(ev1) * 1e3 / 50
-    print(f"per-XCD span first wave start -> last wave end: {min(spans)} .. {max(spans)} ticks; kernel {us:.1f} us per launch -> {max(spans) / us / 1e3:.2f} ticks per ns; "
-          f"waves of XCD 7 starting > 5 k ticks after its first: {late:.2f}")
-    names = ["staged", "fc1", "gru mfma", "gates", "hidden stored", "fc2", "argmax/q"]
+    print(f"kernel {us:.1f} us per launch -> {(rel + life).max() / us / 1e3:.2f} ticks per ns if the launch is first start -> last end")
+    if "--fc1" in sys.argv:   # -DRG_ACTOR_STAMPS_FC1 build: slot 4 = fc1's operands arrived, slot 3 = its MFMAs done, slot 1 = fc1 + staging + barrier
+        print("   cumulative ticks: operands arrived %.0f, fc1 MFMAs done %.0f, Y / Hs written + barrier %.0f, GRU products %.0f, fc2 partials %.0f, end %.0f"
+              % tuple(raw[:, i].mean() for i in (4, 3, 1, 2, 5, 6)))
+        continue
+    raw[:, 0] = 0
+    names = ["(where)", "fc1", "gru mfma", "gates", "hidden stored", "fc2", "argmax/q"]
     d = np.diff(np.concatenate([np.zeros((waves, 1)), st], axis=1), axis=1)
-    print(f"E {E} H {H}: {waves} waves; s_memtime ticks (100 MHz) per phase, mean over waves [mean of wave 0 of each tile]:")
+    print(f"E {E} H {H}: {waves} waves; s_memtime ticks per phase, mean over waves [mean of wave 0 of each tile]:")
     for i, n in enumerate(names):
         print(f"   {n:14s} {d[:, i].mean():8.1f}   [{d[::H // 32, i].mean():8.1f}]   cumulative {st[:, i].mean():8.1f}")
