@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS = 157.3, 2500.0   # dense matrix peaks (MI355X_MICROARCH.md; never the 2:1-sparsity figures)
 
 
-PMC_PROFILE = os.path.join("profiles", "r3_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
-PMC_FALLBACKS = (os.path.join("profiles", "r2_final_pmc_summary.csv"), os.path.join("profiles", "r2a_xcd_pmc_summary.csv"))
+PMC_PROFILE = os.path.join("profiles", "r4_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
+PMC_FALLBACKS = (os.path.join("profiles", "r3_final_pmc_summary.csv"), os.path.join("profiles", "r2_final_pmc_summary.csv"))
 HEADLINE_KERNEL = "rg::step_kernel<0, 8, false, 5, false"   # <PCP, GW 8, step, N 5, single launch[, no gymma block]>
 HEADLINE_GRID = 1024 * 64                                     # 4096 envs at 4 per wavefront: 1024 one-wave workgroups
 # rocprofv3's FETCH_SIZE on gfx950 reports half the bytes read, in every access shape of the step kernels (4 B per lane,
