@@ -136,3 +136,27 @@ def test_shipped_resources_lane_group(shipped):
         hits = {k: r for k, r in _res(shipped, f"2rg11step_kernelILi{scn}ELi{gw}ELb0ELi{nt}ELb0E").items()}
         for k, r in hits.items():
             assert r["spill"] == 0 and r["scratch"] <= 128 and r["occupancy"] >= 3, (k, r)
+
+
+def test_exec_prologue_check_on_real_compiler_output(tmp_path):
+    """The detector on what THIS compiler emits for the instantiation ROCm 7.2 miscompiled (tools/n7_bisect/tpe_probe.hip:
+    MaterialTransport, N = 7): clean with the flags that always passed, one finding with `-O3 -fno-slp-vectorize` -- the block
+    whose VGPR -> AGPR saves sit above the exec restore.  A compiler that no longer produces the pattern skips the second half."""
+    import sys
+    from marbler_amd import build as hip_build
+    try:
+        hipcc = hip_build.hipcc_path()
+    except RuntimeError:
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_scan
+    found = {}
+    for tag, flags in (("good", ["-O3"]), ("bad", ["-O3", "-fno-slp-vectorize"])):
+        lib = str(tmp_path / f"probe_{tag}.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "-shared",
+                               os.path.join(ROOT, "tools", "n7_bisect", "tpe_probe.hip"), "-o", lib] + flags)
+        found[tag] = [m for r in isa_scan.scan_library(lib).values() for m in r["exec_prologue"]]
+    assert found["good"] == []
+    if not found["bad"]:
+        pytest.skip("this compiler does not produce the pattern for the known-bad flag set any more")
+    assert any("v_accvgpr_write" in m or "vector instruction" in m for m in found["bad"]), found["bad"]
