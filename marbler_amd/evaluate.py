@@ -106,7 +106,7 @@ class BatchedActor(object):
         return self._ws
 
     def forward_fused(self, obs, hidden, append_agent_id=True, restart=None, q_out=None, actions_out=None):
-        """One actor step for all E x N agents in one launch (rg_actor_forward, f32 MFMA).
+        """One actor step for all E x N agents in one launch (rg_actor_forward: the matrix cores; GRU on bfloat16 planes unless pack_gru says otherwise).
         obs [E,N,D] f32; hidden [E,N,H] f32 updated IN PLACE; restart [E] uint8 (nonzero = start that
         env's hidden state from zero) or None.  Returns (q [E,N,A], actions [E,N] int32)."""
         import ctypes as C

@@ -85,3 +85,50 @@ def test_fused_actor_on_the_reference_vectors(name):
         for e in range(E):
             assert np.abs(q[e].cpu().numpy() - g["q"][t]).max() < 1e-5
             assert np.abs(hidden[e].cpu().numpy() - g["h"][t]).max() < 1e-5
+
+
+def _draw_actor_case(rng):
+    H = int(rng.choice([64, 128]))
+    shared = bool(rng.rand() < 0.6)
+    N = int(rng.randint(1, 9))
+    append = bool(rng.rand() < 0.6)
+    D = int(rng.randint(1, 64 - (N if append else 0) + 1))          # input width D (+ N) <= 64
+    A = int(rng.choice([1, 2, 5, 7, 20, 31, 32]))
+    E = int(rng.choice([1, 2, 31, 32, 33, 100, 257]))
+    use_rnn = bool(rng.rand() < 0.8)
+    pack = [True, "f32", False][int(rng.randint(0, 3))]
+    return shared, H, E, N, D, A, use_rnn, append, pack
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fused_actor_random_shapes(seed):
+    """Shapes nobody listed: every input width up to 64 (ragged fc1 rows, agent id on or off), 1 ... 32 actions (fc2's padded tile,
+    the all-thread arg-max), ragged and tiny batches, shared / per-agent weights, GRU in all three weight forms / the MLP layer --
+    against the torch evaluation: 1e-5 on q and hidden, greedy actions equal where the top two values are 1e-4 apart."""
+    from marbler_amd.evaluate import BatchedActor
+    rng = np.random.RandomState(7000 + seed)
+    shared, H, E, N, D, A, use_rnn, append, pack = _draw_actor_case(rng)
+    dev = "cuda:0"
+    I = D + (N if append else 0)
+    actor = BatchedActor(_random_actor(1 if shared else N, I, H, A, use_rnn, seed), N, use_rnn=use_rnn, device=dev, pack_gru=pack)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    hidden = torch.rand(E, N, H, generator=g, device=dev) * 2 - 1
+    h_ref = hidden.clone()
+    eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
+    for step in range(2):
+        obs = torch.rand(E, N, D, generator=g, device=dev) * 3 - 1.5
+        restart = (torch.rand(E, generator=g, device=dev) < 0.3).to(torch.uint8)
+        fresh = restart.bool()[:, None, None]
+        obs_seen = torch.where(fresh, torch.zeros_like(obs), obs)
+        q_ref, h_ref = actor.forward(torch.cat([obs_seen, eye], dim=2) if append else obs_seen, torch.where(fresh, torch.zeros_like(h_ref), h_ref))
+        q, act = actor.forward_fused(obs, hidden, append_agent_id=append, restart=restart)
+        torch.cuda.synchronize()
+        case = (shared, H, E, N, D, A, use_rnn, append, pack, step)
+        assert float((q - q_ref).abs().max()) < 1e-5, case
+        assert float((hidden - h_ref).abs().max()) < 1e-5, case
+        if A > 1:
+            top2 = q_ref.topk(2, dim=2).values
+            clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+            assert torch.equal(act[clear].long(), q_ref.argmax(dim=2)[clear]), case
+        else:
+            assert int(act.abs().sum()) == 0, case
