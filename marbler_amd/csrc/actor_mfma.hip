@@ -131,7 +131,10 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     auto row_of = [&](int i) { return shared ? base + i : (base + i) * N + set; };  // flat row index of tile row i
     auto row_ok = [&](int i) { return shared ? (base + i) < R : (base + i) < E; };
     const float *W1 = a.w.w1 + static_cast<size_t>(set) * H * I, *B1 = a.w.b1 + static_cast<size_t>(set) * H;
-    const float *Wih = a.w.wih + static_cast<size_t>(set) * 3 * H * H, *Bih = a.w.bih + static_cast<size_t>(set) * 3 * H;
+    // (use_rnn = 0: the wih / bih slots hold ONE H x H layer per set, not three gates -- a non-shared MLP actor, the reference's
+    // mappo_ns, read past its arrays with the GRU's stride until round 4's shape fuzz)
+    const int GR = a.w.use_rnn ? 3 * H : H;
+    const float *Wih = a.w.wih + static_cast<size_t>(set) * GR * H, *Bih = a.w.bih + static_cast<size_t>(set) * GR;
     const float *Whh = a.w.whh + static_cast<size_t>(set) * 3 * H * H, *Bhh = a.w.bhh + static_cast<size_t>(set) * 3 * H;
     const float *W2 = a.w.w2 + static_cast<size_t>(set) * A * H, *B2 = a.w.b2 + static_cast<size_t>(set) * A;
 

@@ -37,6 +37,7 @@ def _random_actor(n_sets, I, H, A, use_rnn, seed):
     (False, 64, 130, 5, 16, 5, True, False),     # rnn_ns: one network per agent, no agent id
     (True, 128, 33, 8, 18, 5, False, True),      # use_rnn = False
     (False, 128, 1, 3, 30, 5, True, False),      # a single env, ragged tile
+    (False, 128, 50, 4, 9, 20, False, False),    # the zoo's MaterialTransport mappo_ns: one MLP-layer network per agent (round 4: its weight stride)
 ])
 def test_fused_actor_matches_torch(shared, H, E, N, D, A, use_rnn, append):
     from marbler_amd.evaluate import BatchedActor
