@@ -485,6 +485,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="skip the graph_replay side measurement (profiling runs: its launches would mix into the headline kernel's row)")
     ap.add_argument("--scenario", default="PredatorCapturePrey")
+    ap.add_argument("--spinup-ms", type=float, default=250.0,
+                    help="untimed step launches before reset() + the W warm-up steps, so that a GPU that idled while the host did the CPU "
+                         "baseline (or while the previous process exited) is at its clocks when the warm-up starts; 0 = none")
     ap.add_argument("--dist-backend", default=None, help="nccl (default, = RCCL) | gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (a 1-GPU box); never for a measured run")
@@ -557,6 +560,15 @@ def main():
     ptrs = [actions[i].data_ptr() for i in range(n_batches)]
     env.reset()
     step = env.step_raw
+    if args.spinup_ms > 0:   # not part of W or K: the same launches on scratch state, then the episode starts over
+        t_spin = time.perf_counter()
+        i = 0
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            for _ in range(64):
+                step(ptrs[i % n_batches])
+                i += 1
+            torch.cuda.synchronize(dev)
+        env.reset()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -631,7 +643,7 @@ def main():
                             "(~6 cycles per instruction measured, tools/ubench); launch time = the slowest wave"}
         out = {
             "metric": "env agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "steps": K, "warmup": W, "spinup_ms": args.spinup_ms, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "per_rank_ms_per_step": [round(v[0], 6) for v in per_rank], "per_rank_kernel_ms_per_step": [round(v[1], 6) for v in per_rank],
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scenario}-v0, {E} envs x {N} agents per GPU, random policy, "
