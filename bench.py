@@ -73,6 +73,67 @@ def committed_counters():
     return {}, None
 
 
+def live_counters(args, timeout=150):
+    """The headline kernel's counters MEASURED in this run: three child passes of this same script under `rocprofv3 --pmc`
+    (counters only -- no trace domains --, one small group per pass, as MI355X_MICROARCH.md prescribes), started while this process
+    has not touched the GPU; each child times nothing, it only launches the headline workload.  Returns ({counter: mean per
+    launch of the headline kernel at the headline grid}, description) or ({}, reason) -- the caller falls back to the committed
+    profile (`committed_counters`) and says so.  RG_BENCH_NO_LIVE_COUNTERS=1 skips it."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if os.environ.get("RG_BENCH_NO_LIVE_COUNTERS"):
+        return {}, "skipped (RG_BENCH_NO_LIVE_COUNTERS)"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {}, "rocprofv3 not found"
+    vals = {}
+    child = [sys.executable, os.path.abspath(__file__), "--counters-child", "--steps", "200", "--warmup", "20", "--spinup-ms", "0"]
+    try:
+        for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"]):
+            tmp = tempfile.mkdtemp(prefix="rg_pmc_")
+            try:
+                env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+                r = subprocess.run([rocprof, "--pmc"] + group + ["-d", tmp, "-o", "p", "--"] + child, cwd="/tmp", env=env,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+                dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+                if r.returncode != 0 or not dbs:
+                    return {}, f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode})"
+                c = sqlite3.connect(dbs[0])
+                q = ("select counter_name, avg(v), count(*) from (select counter_name, dispatch_id, sum(value) as v from counters_collection "
+                     "where kernel_name like ? and grid_size = ? group by counter_name, dispatch_id) group by counter_name")
+                for name, v, n in c.execute(q, ("%" + HEADLINE_KERNEL + "%", HEADLINE_GRID)):
+                    if n >= 50:
+                        vals[name] = float(v)
+                c.close()
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+    except Exception as exc:   # a profiler problem must not cost the bench line
+        return {}, f"live counter passes failed: {type(exc).__name__}: {exc}"
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return {}, "the counter passes returned no rows for the headline kernel"
+    return vals, "measured in this run: rocprofv3 --pmc child passes of this script (FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU SQ_WAVES, 220 launches each)"
+
+
+def counters_child(args):
+    """What a `rocprofv3 --pmc` pass of live_counters() runs: the headline workload's launches, nothing timed or printed."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    dev = torch.device("cuda", 0)
+    env = VecRobotariumEnv(args.scenario, args.envs_per_gpu, overrides=bench_overrides(args.scenario), device=dev, seed=0, auto_reset=True)
+    n_act = 20 if args.scenario == "MaterialTransport" else 5
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    actions = torch.randint(0, n_act, (64, args.envs_per_gpu, env.N), generator=gen, device=dev, dtype=torch.int32)
+    env.reset()
+    for i in range(args.steps + args.warmup):
+        env.step_raw(actions[i % 64].data_ptr())
+    torch.cuda.synchronize(dev)
+    env.close()
+
+
 def _port_worker(seconds, seed):
     """One NumPy-port env stepped for `seconds` on this process's core; prints the env-step count."""
     import numpy as np
@@ -484,8 +545,9 @@ def main():
     ap.add_argument("--no-saturated", action="store_true", help="skip the 524288-env side measurement")
     ap.add_argument("--no-graph", action="store_true",
                     help="skip the graph_replay side measurement (profiling runs: its launches would mix into the headline kernel's row)")
+    ap.add_argument("--counters-child", action="store_true", help=argparse.SUPPRESS)   # a rocprofv3 --pmc pass of live_counters()
     ap.add_argument("--scenario", default="PredatorCapturePrey")
-    ap.add_argument("--spinup-ms", type=float, default=250.0,
+    ap.add_argument("--spinup-ms", type=float, default=1000.0,
                     help="untimed step launches before reset() + the W warm-up steps, so that a GPU that idled while the host did the CPU "
                          "baseline (or while the previous process exited) is at its clocks when the warm-up starts; 0 = none")
     ap.add_argument("--dist-backend", default=None, help="nccl (default, = RCCL) | gloo (CPU rehearsal of the N>1 path)")
@@ -510,9 +572,14 @@ def main():
 
     # The CPU baseline runs first, while this process has not touched the GPU: it starts child
     # processes (one env each on the host cores), and nothing is exec'ed after HIP is initialised.
+    if args.counters_child:
+        return counters_child(args)
     cpu_ref = None
+    live, live_src = {}, None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu_ref = cpu_baseline()
+        if args.scenario == "PredatorCapturePrey" and args.envs_per_gpu == ENVS_PER_GPU and args.gpus == 1:
+            live, live_src = live_counters(args)   # (also before this process touches the GPU)
 
     import torch
     import torch.distributed as dist
@@ -630,6 +697,11 @@ def main():
         achieved = bytes_per_launch / (gpu_ms_total / K * 1e-3) / 1e9 if bytes_per_launch else None
         counters, counters_src = committed_counters() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU) \
             else ({}, None)
+        counters_kind = "from_committed_profile"
+        if live:
+            counters, counters_src, counters_kind = live, live_src, "measured_in_this_run"
+        elif live_src:
+            counters_src = f"{counters_src} (live passes: {live_src})"
         traffic = (FETCH_SIZE_SCALE * counters["FETCH_SIZE"] + WRITE_SIZE_SCALE * counters["WRITE_SIZE"]) * 1024.0 if counters else None
         kernel_s = gpu_ms_total / K * 1e-3
         valu = None
@@ -651,7 +723,7 @@ def main():
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_kind": "from_committed_profile (rocprofv3 --pmc passes of this command; not measured in this run): "
+                         "traffic_kind": counters_kind + " (rocprofv3 --pmc passes, separate from the timed region): "
                                          "2 x FETCH_SIZE + WRITE_SIZE, the factors calibrated on known byte counts in the kernels' own "
                                          "access shapes (profiles/r3_hbm_calibration.csv); an upper bound: 0.17 MB reported (0.17-0.35 MB of "
                                          "bytes, factor uncalibrated for instruction fetches) is the kernel's own instructions, fetched by each "
