@@ -160,3 +160,33 @@ def test_exec_prologue_check_on_real_compiler_output(tmp_path):
     if not found["bad"]:
         pytest.skip("this compiler does not produce the pattern for the known-bad flag set any more")
     assert any("v_accvgpr_write" in m or "vector instruction" in m for m in found["bad"]), found["bad"]
+
+
+def test_dot_hazard_scan_fails_when_the_s_nop_is_removed(tmp_path):
+    """The other direction of the DOT check: the same kernel source with `s_nop 2` deleted from dot2_batch (a copy of the
+    headers in a temporary directory) must produce findings -- the scan is not vacuous on real compiler output."""
+    import shutil
+    import sys
+    from marbler_amd import build as hip_build
+    try:
+        hipcc = hip_build.hipcc_path()
+    except RuntimeError:
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_scan
+    inc = tmp_path / "csrc"
+    inc.mkdir()
+    for h in os.listdir(CSRC):
+        if h.endswith(".h"):
+            text = open(os.path.join(CSRC, h)).read().replace('#include "../../include/robogym.h"', f'#include "{os.path.join(ROOT, "include", "robogym.h")}"')
+            if h == "device_common.h":
+                n = text.count("s_nop 2")
+                text = text.replace('\\n\\ts_nop 2"', '"').replace('\\ts_nop 2"', '"')
+                assert text.count("s_nop 2") < n
+            (inc / h).write_text(text)
+    lib = str(tmp_path / "nonop.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-I", str(inc), "-shared",
+                           os.path.join(ROOT, "tools", "n7_bisect", "tpe_probe.hip"), "-DPROBE_N=5", "-DPROBE_SCN=RG_SCN_PREDATOR_CAPTURE_PREY", "-o", lib])
+    rep = isa_scan.scan_library(lib)
+    assert sum(r["dots"] for r in rep.values()) > 100
+    assert sum(len(r["dot_hazards"]) for r in rep.values()) > 0
