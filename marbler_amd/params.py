@@ -83,7 +83,8 @@ def make_params(scenario, cfg):
     p.penalize_violations = int(bool(cfg["penalize_violations"]))
     p.shared_reward = int(bool(cfg.get("shared_reward", scenario != "Warehouse")))
     if cfg.get("real_time", False):
-        raise ValueError("real_time: True paces the simulator to wall-clock time (rps sim_in_real_time): not a batched mode")
+        raise ValueError("real_time: True paces the simulator to wall-clock time (rps sim_in_real_time): not a batched mode "
+                         "(the single-env `Wrapper` honours it: marbler_amd/wrapper.py)")
     bc = cfg.get("barrier_certificate", "safe")                # roboEnv.py:15-18
     if bc not in ("safe", "default"):
         raise ValueError("barrier_certificate must be 'safe' or 'default' (custom closures are not supported)")

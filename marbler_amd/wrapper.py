@@ -21,6 +21,7 @@ EPyMARL's parallel runner builds from one key -- replay the same initial conditi
 TimeLimit / other wrappers read `metadata`, `reward_range`, `spec`.
 """
 import random as _pyrandom
+import time as _time
 
 import numpy as np
 import torch
@@ -45,9 +46,16 @@ class _ScenarioFacade(object):
     args, get_action_space / get_observation_space, reset, step."""
 
     def __init__(self, env_name, config_path, device):
+        # `real_time: True` (rps sim_in_real_time: every simulator iteration waits until 0.033 s have passed since the one before,
+        # rps Robotarium.step) is a property of this single-env facade, not of the batched engine: the step is computed at once
+        # and step() returns when the reference's would have -- update_frequency x 0.033 s after it was called.  (A step that
+        # ends early in a violation is paced like a full one: the exit iteration is not part of what a step returns.)
+        from .params import load_config
+        self._real_time = bool(load_config(env_name, config_path).get("real_time", False))
         self.vec = VecRobotariumEnv(env_name, 1, config_path=config_path, device=device, auto_reset=False,
-                                    reference_reset_obs=True, seed=None)   # seed -1: a fresh key per instance
-        cfg = self.vec.cfg
+                                    reference_reset_obs=True, seed=None,   # seed -1: a fresh key per instance
+                                    overrides={"real_time": False} if self._real_time else None)
+        cfg = dict(self.vec.cfg, real_time=self._real_time)
         self._rng = self._pyrandom = None
         if cfg.get("seed", -1) != -1:
             self.vec.seed = int(cfg["seed"])
@@ -75,7 +83,12 @@ class _ScenarioFacade(object):
         return [[0] * self.vec.D] * self.num_robots
 
     def step(self, actions_):
+        t0 = _time.monotonic()
         h_obs, h_rew, terminated, viol, rem, h_dist = self.vec.host_step(actions_)
+        if self._real_time:
+            wait = self.vec.params.update_frequency * self.vec.params.time_step - (_time.monotonic() - t0)
+            if wait > 0:
+                _time.sleep(wait)
         obs = h_obs.astype(np.float64)
         out = {}
         if viol and self._scenario == "Simple":

@@ -242,3 +242,41 @@ def test_gymma_step_outputs_survive_the_next_step():
     assert int(want[1].sum()) > 0 and int(want[2].sum()) > 0
     # the aliasing form: every kept entry is the same buffer = the last step
     assert torch.equal(kept[True][1], want[1][-1:].expand_as(want[1]))
+
+
+def test_real_time_paces_the_single_env_wrapper():
+    """`real_time: True` (rps sim_in_real_time: 0.033 s of wall clock per simulator iteration): the facade returns a step no sooner than
+    update_frequency x 0.033 s after the call, with the same values as the unpaced env; the batched engine still refuses the key."""
+    import time
+    from marbler_amd import VecRobotariumEnv, Wrapper
+    from marbler_amd.params import default_config_path, load_config
+    cfg = load_config("Warehouse", default_config_path("Warehouse"), {"real_time": True, "update_frequency": 6, "seed": 3})
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        yaml.safe_dump(cfg, f)
+        path = f.name
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        yaml.safe_dump(dict(cfg, real_time=False), f)
+        path_fast = f.name
+    try:
+        slow, fast = Wrapper("Warehouse", path), Wrapper("Warehouse", path_fast)
+        assert slow.env.args.real_time is True
+        with pytest.raises(ValueError):
+            VecRobotariumEnv("Warehouse", 4, config_path=path)
+    finally:
+        os.unlink(path)
+        os.unlink(path_fast)
+    slow.reset()
+    fast.reset()
+    acts = [1, 0, 3, 2, 1, 0]
+    slow.step(acts)                                   # (first call: lazily created host buffers)
+    fast.step(acts)
+    t0 = time.monotonic()
+    o1, r1, d1, i1 = slow.step(acts)
+    dt_slow = time.monotonic() - t0
+    t0 = time.monotonic()
+    o2, r2, d2, i2 = fast.step(acts)
+    dt_fast = time.monotonic() - t0
+    assert dt_slow >= 6 * 0.033 - 1e-3 and dt_slow < 6 * 0.033 + 0.05 and dt_fast < 0.05, (dt_slow, dt_fast)
+    assert all(np.array_equal(a, b) for a, b in zip(o1, o2)) and r1 == r2 and d1 == d2
+    slow.close()
+    fast.close()
