@@ -259,7 +259,7 @@ struct Stage {
     int nact;     // envs of this wave (64 except in the batch's last wave)
     size_t env0;  // first env of the wave
     size_t e;     // this lane's env (lanes past the end of the batch: its last env)
-#ifdef RG_TPE_GUARD  // diagnostic build (tools/guard_probe.py): a store outside its array is dropped and flagged in
+#ifdef RG_TPE_GUARD  // diagnostic build (tests/guard_probe.py): a store outside its array is dropped and flagged in
     int *flag;    // done_count[0] instead of faulting
     int E;
 #endif

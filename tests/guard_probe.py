@@ -3,13 +3,13 @@
 LDS staging block are bounds-checked: a store outside its array is dropped and flagged in done_count[0] instead of
 faulting), compared with the float32 oracle.
     python -c "from marbler_amd import build; build.build(defines=('RG_TPE_GUARD',), out='marbler_amd/librobogym_guard.so')"
-    python tools/guard_probe.py tests/golden/pcp_n6_capaware.npz"""
+    python tests/guard_probe.py tests/golden/pcp_n6_capaware.npz"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("ROBOGYM_LIB", os.path.join(ROOT, "marbler_amd", "librobogym_guard.so"))
 os.environ["RG_STEP_KERNEL"] = "tpe"
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # (this file lives in tests/: only tests may use the oracle)
 import numpy as np
 import torch
 from helpers import gpu_from_state, load_golden, oracle_from_state, pre_state

@@ -96,6 +96,21 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle/_build" not in src and "liboracle" not in src, f
 
 
+def test_only_tests_smoke_and_the_cpu_baseline_use_the_oracle():
+    """oracle/ is test infrastructure: besides tests/ only __graft_entry__ (build() compiles it, smoke() checks against it) and
+    bench.py's cpu_baseline leg may import it -- not the probes under tools/, not examples/, not the import-name shim."""
+    for sub in ("tools", "examples", "robotarium_gym", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".cpp", ".hip", ".h")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+                    assert "liboracle" not in src and "oracle/_build" not in src, os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)(from|import)\s+oracle\b", bench, flags=re.M):
+        assert len(m.group(1)) >= 4, "bench.py imports the oracle at module level"    # only inside cpu_baseline() and its workers
+
+
 def test_params_follow_the_reference_configs():
     from marbler_amd import load_config, make_params
     p = make_params("PredatorCapturePrey", load_config("PredatorCapturePrey"))

@@ -38,7 +38,7 @@ def _report(src, defines=()):
 
 def test_diagnostic_builds_of_the_thread_per_env_kernel_still_compile():
     """-DRG_STAMPS -DRG_STAMPS_EPI (phase stamps, tools/stamp_probe.py / epi_probe.py), -DRG_TPE_GUARD (bounds-checked
-    staged stores, tools/guard_probe.py) and -DRG_TPE_DIAG (sweep / replay masks, tools/tpe_diag.py) are never shipped
+    staged stores, tests/guard_probe.py) and -DRG_TPE_DIAG (sweep / replay masks, tools/tpe_diag.py) are never shipped
     and only built by hand: one compile with all of them keeps the macros from rotting."""
     rep = _report("tpe_pcp5.hip", defines=("RG_STAMPS", "RG_STAMPS_EPI", "RG_TPE_GUARD", "RG_TPE_DIAG"))
     assert len(rep) == 3
