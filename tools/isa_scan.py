@@ -14,8 +14,8 @@ Three checks, each born from an incident of this repo:
                      the exec restore, because an SGPR copy of the earlier SGPR allocation sat in front of it and ended
                      what LLVM takes for the block prologue.  The saves then run under the `then` branch's exec mask only;
                      lanes outside it later "restore" stale AGPR contents (a float multiplier in an integer sweep counter).
-                     The check: no vector instruction between a branch-target label and the exec restore of a mask that was
-                     not saved inside that block.
+                     The check: no vector instruction between a branch-target label and the exec restore (`s_or_b64 exec, exec, sN` of
+                     SI_END_CF, `s_or_saveexec_b64 sN, sN` of SI_ELSE) of a mask that was not saved inside that block.
 * `resources`     -- VGPR / AGPR / scratch / LDS / occupancy from the code object's own metadata.
 """
 import os
@@ -158,9 +158,12 @@ def exec_prologue(insts):
     index_of = {it.addr: k for k, it in enumerate(insts)}
     bad = []
     for i, it in enumerate(insts):
-        if it.op != "s_or_b64" or not it.args.replace(" ", "").startswith("exec,exec,"):
+        if it.op == "s_or_b64" and it.args.replace(" ", "").startswith("exec,exec,"):
+            mask = it.args.split(",")[2].strip()          # SI_END_CF
+        elif it.op == "s_or_saveexec_b64":
+            mask = it.args.split(",")[1].strip()          # SI_ELSE: exec <- exec | mask at the head of the `else` block
+        else:
             continue
-        mask = it.args.split(",")[2].strip()
         seen, j, at_label, nested = [], i, it.addr in targets, []
         while not at_label and j > 0:
             j -= 1
