@@ -22,7 +22,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     procs = []
     for arg in sys.argv[2:]:
         name, flags = arg.split("=", 1)
-        # names starting with "v1": the round-3 kernel, taken from history (git show 932219d:marbler_amd/csrc/actor_mfma.hip > tools/actor_lab/actor_v1.hip)
+        # names starting with "v1": the round-3 kernel; not kept in the tree -- git show 932219d:marbler_amd/csrc/actor_mfma.hip > tools/actor_lab/actor_v1.hip
         src = os.path.join(HERE, "actor_v1.hip") if name.startswith("v1") else os.path.join(ROOT, "marbler_amd", "csrc", "actor_mfma.hip")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "marbler_amd", "csrc"),
                "-shared", src, "-o", os.path.join(OUT, f"actor_{name}.so")] + flags.split()

@@ -3,7 +3,6 @@
 // tested on the GPU in one call (tools/n7_bisect/run_probe.py).  Round-4 investigation of the MaterialTransport N = 7
 // miscompute under -O3 -fno-slp-vectorize (DESIGN.md / NOTEBOOK.md); not part of the library.
 #include <string.h>
-#define RG_TPE_HI
 #include "step_tpe.h"
 
 #ifndef PROBE_SCN
