@@ -10,14 +10,16 @@
 //   marbler_amd/evaluate.py): every float32 value is carried as THREE bfloat16 planes (see split8 below) and a float32
 //   product becomes six plane products on v_mfma_f32_32x32x16_bf16 (32 cycles for K = 16), 6/16 of the float32 MFMA time, with
 //   an error below a float32 dot product's own roundings.  gru_packed == 0 / 1: f32-input MFMA (v_mfma_f32_32x32x2_f32, 64
-//   cycles for K = 2), exact float32 products.  Round 4 at 4096 x 4 rows, hidden 128: 27.8 us per launch against 47-50 us
-//   (119.8 TFLOP/s of the network's arithmetic = 76 % of the dense float32 MFMA peak; 8192 x 4: 86 %).
-// * A operands (activations) are read from LDS as float4 blocks; B operands (weights) stream from L2 in the order a pack routine
-//   wrote them (1 KB per load instruction).  fc1's small ragged matrix and the observation rows are read as they lie, by a
-//   ROLLED loop (the layer unrolled was ~600 instructions of cold code at the head of every launch: the instruction fetch made
-//   the first operands arrive 13-15 k cycles into the wave).
-// * Two [32][H] LDS images with an XOR swizzle instead of padding: 32 KB per tile, TWO tiles per CU (the runtime schedules
-//   against 64 KB of LDS per CU; the padded 42.5 KB of rounds 1-3 let one tile run per CU, two rounds for the benchmark batch).
+//   cycles for K = 2), exact float32 products.  Round 4 at 4096 x 4 rows, hidden 128: 25.2 us per launch against 47-50 us
+//   (132 TFLOP/s of the network's arithmetic = 84 % of the dense float32 MFMA peak).
+// * A operands (activations) are read from LDS; B operands of the GRU (weights) stream from L2 in the order a pack routine
+//   wrote them (1 KB per load instruction), a ring of groups ahead of the MFMAs, held in place by scheduling fences.  fc1's
+//   small ragged operands are fetched once per tile, coalesced, and staged in LDS (inputs up to 32 wide; wider ones are read
+//   as they lie by a ROLLED loop: unrolled, the layer was ~600 instructions of cold code at the head of every launch).
+// * Two [32][H] LDS images with an XOR swizzle instead of padding, and 256 registers per lane (amdgpu_waves_per_eu): TWO tiles
+//   per CU, one wave of each per SIMD.  (Rounds 1-3 ran one tile per CU -- 352 registers per lane; the 42.5 KB of padded LDS
+//   they also used was NOT the limit, although hipOccupancyMaxActiveBlocksPerMultiprocessor, which reckons with 64 KB of LDS
+//   per CU, says so: the same kernel with its LDS padded to 52 KB still runs two tiles per CU at the same speed.)
 // * Layer outputs come out of the MFMA with the column on the lane and 16 rows in registers (C/D map: col = lane & 31,
 //   row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); the gate arithmetic is elementwise in that layout and one LDS write turns it
 //   into the next layer's A image.  fc2's K range is split over the tile's wavefronts, the partial tiles meet in LDS, and all
@@ -91,12 +93,14 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 #else
 #define RG_ASTAMP(i)
 #endif
+#ifdef RG_ACTOR_STAMPS_FC1   // the head of the wave in detail (slots 2..5; the later phases' stamps are left out)
+#define RG_HSTAMP(i) RG_ASTAMP(i)
+#else
+#define RG_HSTAMP(i)
+#endif
 
-// Two [TM][H] images in LDS with pitch exactly H -- 32 KB per workgroup at H = 128, so that TWO workgroups fit the 64 KB of
-// LDS per CU this runtime schedules against (round 4: with 42.5 KB -- padded pitch, a third image for the inputs -- only one
-// workgroup ran per CU, the chip did the 512 tiles of the benchmark batch in two rounds and one tile's serial phases never
-// overlapped another tile's matrix work).  Bank conflicts are avoided by an XOR swizzle of the 16-byte block index with the
-// row instead of padding: block b of row i lives at block b ^ (i & 7).  The eight lanes of an LDS lane group read the
+// Two [TM][H] images in LDS with pitch exactly H.  Bank conflicts are avoided by an XOR swizzle of the 16-byte block index
+// with the row instead of padding: block b of row i lives at block b ^ (i & 7).  The eight lanes of an LDS lane group read the
 // same logical block of eight consecutive rows -> eight different physical blocks -> all 32 banks.
 template <int H>
 __device__ __forceinline__ int swz(int i, int k) { return i * H + ((((k >> 2) ^ (i & 7)) << 2) | (k & 3)); }
@@ -145,14 +149,10 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     for (int m = 0; m < HV; ++m) {
         const int idx = tid + NTHREADS * m, i = idx / (H / 4), k4 = idx % (H / 4);
         // (the loads do not wait for the restart flag: one memory round trip, the flag is applied to what comes back)
-        const bool ok = row_ok(i);
-        const int r = ok ? row_of(i) : 0;
+        const int r = row_ok(i) ? row_of(i) : 0;
         hv[m] = *reinterpret_cast<const float4 *>(a.hidden + static_cast<size_t>(r) * H + 4 * k4);
-        // a restarted env starts from the reference's reset(): zero hidden state, zero observation (PredatorCapturePrey.py:136)
-        const bool keep = ok && !(a.restart && a.restart[r / N] != 0);
-        if (!keep) hv[m] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-
+    RG_HSTAMP(2);  // (head) hidden-state loads issued
     auto zero16 = [] {
         floatx16 z;
 #pragma unroll
@@ -168,23 +168,90 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     };
     auto crow = [&](int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; };  // tile row of accumulator register `reg`
 
-    // ---- fc1 + ReLU: Y = relu(X W1^T + b1); this wave's 32 columns.  The layer is small and its rows are ragged (I is not a
-    // multiple of 4): scalar operand loads straight from memory (the observation row of tile row `col` + the one-hot agent
-    // id; every wave of the tile reads the same 32 short rows: L1 hits), zero beyond I, all in flight before the first product.
+    // ---- fc1 + ReLU: Y = relu(X W1^T + b1); this wave's 32 columns.
+    // The MFMA wants its operands one ROW per lane (A: observation row `col`, B: weight row n), and read that way from memory
+    // every load instruction touches 32 rows = 32 cache lines for 4 bytes each, by every wave of the tile again: ~6 000 line
+    // look-ups per tile, and the wave spent 8 k of its 45 k cycles in this small layer waiting on the CU's L1 (head stamps,
+    // round 4).  So for inputs up to 32 wide the tile's X block and each wave's 32 rows of W1 are fetched ONCE, coalesced
+    // (TPRX neighbouring lanes share a row; W1 as a flat run of float4), and the operands are read from LDS.  X is staged as
+    // the layer's final input -- restart flag applied, one-hot agent id appended, zero beyond I -- in what becomes Y; the W1
+    // chunks in what becomes the old hidden state's image.  Wider inputs (up to MAX_IP) read memory directly, as before.
+    constexpr int TPRX = NTHREADS / TM;   // threads per tile row in the staging pass (8 or 4)
+    constexpr int XP = 33;                // staged X pitch in floats (odd: the 32 rows fall into 32 banks)
+    constexpr int WCH = TM * 32;          // floats per wave's W1 chunk (32 rows x at most 32 inputs)
+    static_assert(TM * XP + TM <= TM * H && (H / 32) * WCH <= TM * H, "the staging areas must fit the two LDS images");
+    float *const Xs = Y;
+    int *const live_s = reinterpret_cast<int *>(Y + TM * XP);   // per tile row: 1 = takes its observation and hidden state
+    float *const Ws = Hs + cb * WCH;
+    const bool staged = IP <= 32;
+    const int n = cb * 32 + col;
+    floatx16 acc = zero16();
+    const float b1 = B1[n];
     {
-        const int n = cb * 32 + col;
-        floatx16 acc = zero16();
+        // this thread's tile row in the staging pass
+        const int srow = tid / TPRX, part = tid % TPRX;
+        const bool ok = row_ok(srow);
+        const int r = ok ? row_of(srow) : 0;
+        const int env = shared ? r / N : base + srow, agent = shared ? r - env * N : set;
+        const bool live = ok && !(a.restart && a.restart[ok ? env : 0] != 0);
+        // a restarted env starts from the reference's reset(): zero hidden state, zero observation (PredatorCapturePrey.py:136)
+        if (part == 0) live_s[srow] = live ? 1 : 0;
+        if (staged) {
+            const float *xrow = a.obs + static_cast<size_t>(r) * a.D;
+            const int id_k = (ok && a.append_agent_id) ? a.D + agent : -1;   // where this row's one-hot agent id sits
+            float xv[32 / TPRX];
+            u32x4 wv[4];
+#pragma unroll
+            for (int m = 0; m < 32 / TPRX; ++m) {
+                const int k = part + TPRX * m;
+                xv[m] = (ok && k < a.D) ? xrow[k] : 0.0f;   // (not gated by the restart flag: that would be a second round trip)
+            }
+            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W1 + static_cast<size_t>(cb) * 32 * I);   // rows 32 cb .. 32 cb + 31: 8 I float4
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int f4 = lane + 64 * m;
+                wv[m] = f4 < 8 * I ? wsrc[f4] : u32x4{0u, 0u, 0u, 0u};
+            }
+            RG_HSTAMP(3);  // (head) staging loads requested
+#pragma unroll
+            for (int m = 0; m < 32 / TPRX; ++m) {
+                const int k = part + TPRX * m;
+                Xs[srow * XP + k] = k < a.D ? (live ? xv[m] : 0.0f) : (k == id_k ? 1.0f : 0.0f);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int f4 = lane + 64 * m;
+                if (f4 < 8 * I) *reinterpret_cast<u32x4 *>(Ws + 4 * f4) = wv[m];
+            }
+        }
+    }
+    __syncthreads();   // X, the flags (and, wave by wave, the W1 chunks) are in LDS
+    int keep[HV];      // (read now: the flags' place is overwritten by Y below)
+#pragma unroll
+    for (int m = 0; m < HV; ++m) keep[m] = live_s[(tid + NTHREADS * m) / (H / 4)];
+    const int steps = IP / 2;   // per lane half; IP is a multiple of 8
+    if (staged) {
+#pragma unroll 1
+        for (int kk0 = 0; kk0 < steps; kk0 += 4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = half * steps + kk0 + c;
+                const float x = Xs[col * XP + k];
+                const float w = k < I ? Ws[col * I + k] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, w, acc, 0, 0, 0);
+            }
+        }
+    } else {
+        // scalar operand loads straight from memory (the observation row of tile row `col` + the one-hot agent id), zero beyond I
         const bool ok = row_ok(col);
         const int r = ok ? row_of(col) : 0;
         const int env = r / N, agent = r - env * N;
         const float *xrow = a.obs + static_cast<size_t>(r) * a.D;
         const float *wrow = W1 + static_cast<size_t>(n) * I;
-        const bool live = ok && !(a.restart && a.restart[env] != 0);
-        const int id_k = (ok && a.append_agent_id) ? a.D + agent : -1;   // where this row's one-hot agent id sits
+        const bool live = live_s[col] != 0;
+        const int id_k = (ok && a.append_agent_id) ? a.D + agent : -1;
         // A ROLLED loop, four k-steps per trip: unrolled over the widest input (32 steps, two predicated loads each) the layer was
-        // ~600 instructions of straight-line code that every CU fetches cold at the start of every launch -- the instruction
-        // fetch, not the data, made the first operands arrive 13-15 k cycles into a 52 k-cycle wave (round 4, -DRG_ACTOR_STAMPS_FC1)
-        const int steps = IP / 2;   // per lane half; IP is a multiple of 8
+        // ~600 instructions of straight-line code that every CU fetches cold at the start of every launch (round 4)
 #pragma unroll 1
         for (int kk0 = 0; kk0 < steps; kk0 += 4) {
             float xq[4], wq[4];
@@ -201,21 +268,40 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, wq[c], acc, 0, 0, 0);
             }
         }
-        const float b = B1[n];
-#ifdef RG_ACTOR_STAMPS_FC1
-        asm volatile("" ::"v"(acc), "v"(b));
-        RG_ASTAMP(3);
-#endif
-#pragma unroll
-        for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = fmaxf(acc[r_] + b, 0.0f);
     }
+#ifdef RG_ACTOR_STAMPS_FC1
+    asm volatile("" ::"v"(acc), "v"(b1));
+    RG_HSTAMP(4);  // (head) fc1's products and its bias have arrived
+#endif
+    __syncthreads();   // every wave is done with the staged operands: their place becomes Y and the old hidden state
+#pragma unroll
+    for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = fmaxf(acc[r_] + b1, 0.0f);
 #pragma unroll
     for (int m = 0; m < HV; ++m) {
         const int idx = tid + NTHREADS * m, i = idx / (H / 4), k4 = idx % (H / 4);
-        *reinterpret_cast<float4 *>(&Hs[swz4<H>(i, k4)]) = hv[m];
+        *reinterpret_cast<float4 *>(&Hs[swz4<H>(i, k4)]) = keep[m] ? hv[m] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    RG_HSTAMP(5);  // (head) Y and the old hidden state written to LDS
     __syncthreads();
     RG_ASTAMP(1);  // fc1 done, old hidden state staged
+
+    // fc2's operands are requested behind the recurrent layer's products, ahead of its elementwise tail: asked for where they
+    // are used, behind two barriers, each is a trip to L2 with nothing to hide it
+    float4 w2v[4];
+    constexpr int TPR = NTHREADS / TM, CPT = 32 / TPR;   // arg-max pass: TPR threads per tile row, CPT action columns each
+    float b2v[CPT];
+    auto request_fc2 = [&] {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            w2v[q4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (col < A) w2v[q4] = *reinterpret_cast<const float4 *>(W2 + static_cast<size_t>(col) * H + cb * 32 + half * 16 + 4 * q4);
+        }
+#pragma unroll
+        for (int c_ = 0; c_ < CPT; ++c_) {
+            const int c = (tid % TPR) * CPT + c_;
+            b2v[c_] = c < A ? B2[c] : 0.0f;
+        }
+    };
 
     // ---- recurrent layer
     float hn[16];       // the new hidden state in accumulator layout (the old one is still an operand)
@@ -223,6 +309,15 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         {
             const int j = cb * 32 + col;
             floatx16 gi[3], gh[3];
+            float bir, biz, bin, bhr, bhz, bhn;
+            auto request_biases = [&] {
+                bir = Bih[j], biz = Bih[H + j], bin = Bih[2 * H + j];
+                bhr = Bhh[j], bhz = Bhh[H + j], bhn = Bhh[2 * H + j];
+            };
+            if constexpr (SPLIT) {   // requested ahead of the products: behind them the gates would start with a trip to L2
+                request_biases();    // (the float32-MFMA form has no registers to spare for that)
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 gi[g] = zero16();
@@ -243,21 +338,30 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) wl[pl] = *reinterpret_cast<const u32x4 *>(src + pl * 64 * 8);
                 };
-                u32x4 wq[3][3];
-                load_w(0, wq[0]);
-                load_w(1, wq[1]);
+                // PD groups in flight ahead of the one being multiplied.  NOTHING may be scheduled across the fences below: left to
+                // itself the compiler sinks every weight load to just above its first use (fewer live registers) and the stream
+                // waits a trip to L2 per group -- the ring the source described did not exist in the ISA until round 4 looked
+                // (s_waitcnt vmcnt(0..3) before every group; a single wave per SIMD took 56 cycles per MFMA, now 45; two waves
+                // 40 -> 35 against the pipe's 32).  A mask that lets ALU / MFMA / DS instructions cross lets the loads cross too.
+                constexpr int PD = 2, RING = PD + 1;
+                constexpr int FENCE = 0;
+                u32x4 wq[RING][3];
+#pragma unroll
+                for (int t = 0; t < PD; ++t) load_w(t, wq[t]);
+                __builtin_amdgcn_sched_barrier(FENCE);
                 bf16x8 yh, ym, yl, hh_, hm_, hl_;
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
                     const int ks = t / 6, g = (t % 6) >> 1, hh = t & 1;
+                    if (t + PD < NG) load_w(t + PD, wq[(t + PD) % RING]);
+                    __builtin_amdgcn_sched_barrier(FENCE);
                     if (t % 6 == 0) {   // this step's activations, split once for all six products
                         const int k4 = 4 * ks + 2 * half;
                         split8(*reinterpret_cast<const float4 *>(&Y[swz4<H>(col, k4)]), *reinterpret_cast<const float4 *>(&Y[swz4<H>(col, k4 + 1)]), yh, ym, yl);
                         split8(*reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k4)]), *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k4 + 1)]), hh_, hm_, hl_);
                     }
-                    if (t + 2 < NG) load_w(t + 2, wq[(t + 2) % 3]);
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[t % 3][0]), wm = __builtin_bit_cast(bf16x8, wq[t % 3][1]),
-                                 wl = __builtin_bit_cast(bf16x8, wq[t % 3][2]);
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[t % RING][0]), wm = __builtin_bit_cast(bf16x8, wq[t % RING][1]),
+                                 wl = __builtin_bit_cast(bf16x8, wq[t % RING][2]);
                     const bf16x8 xh = hh ? hh_ : yh, xm = hh ? hm_ : ym, xl = hh ? hl_ : yl;
                     floatx16 acc = hh ? gh[g] : gi[g];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wm, acc, 0, 0, 0);   // small terms first
@@ -318,10 +422,12 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #ifdef RG_ACTOR_STAMPS
 #pragma unroll
             for (int g = 0; g < 3; ++g) asm volatile("" ::"v"(gi[g]), "v"(gh[g]));
+#ifndef RG_ACTOR_STAMPS_FC1
             RG_ASTAMP(2);  // GRU products
 #endif
-            const float bir = Bih[j], biz = Bih[H + j], bin = Bih[2 * H + j];
-            const float bhr = Bhh[j], bhz = Bhh[H + j], bhn = Bhh[2 * H + j];
+#endif
+            if constexpr (!SPLIT) request_biases();
+            request_fc2();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float rg_ = sigmoidf_((gi[0][r] + bir) + (gh[0][r] + bhr));
@@ -340,6 +446,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                             *reinterpret_cast<const float4 *>(Wih + static_cast<size_t>(j) * H + k0));
             }
             const float b = Bih[j];
+            request_fc2();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hn[r] = fmaxf(acc[r] + b, 0.0f);
         }
@@ -370,21 +477,19 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     // 32 k values = 16 MFMAs each instead of H / 2 on one wavefront while the others wait -- and the partial tiles meet in LDS.
     {
         floatx16 acc = zero16();
-        const bool n_ok = col < A;
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             const int k0 = cb * 32 + half * 16 + kk;
-            float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (n_ok) w = *reinterpret_cast<const float4 *>(W2 + static_cast<size_t>(col) * H + k0);
-            acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k0 >> 2)]), w);
+            acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k0 >> 2)]), w2v[kk >> 2]);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) Y[cb * (TM * 32) + crow(r) * 32 + col] = acc[r];  // Y is free again: NW partial tiles, row-major
     }
     __syncthreads();
+#ifndef RG_ACTOR_STAMPS_FC1
     RG_ASTAMP(5);  // fc2 partial products
+#endif
     {   // every thread: TPR threads per tile row, CPT action columns each; then the greedy action of the row
-        constexpr int TPR = NTHREADS / TM, CPT = 32 / TPR;
         const int i = tid / TPR, sub = tid % TPR;
         const bool ok = row_ok(i);
         const int r = ok ? row_of(i) : 0;
@@ -397,7 +502,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 float v = 0.0f;
 #pragma unroll
                 for (int wv = 0; wv < NW; ++wv) v = v + Y[wv * (TM * 32) + i * 32 + c];
-                v = v + B2[c];
+                v = v + b2v[c_];
                 if (ok && a.q) a.q[static_cast<size_t>(r) * A + c] = v;
                 if (v > best) {  // first maximum, like torch.argmax
                     best = v;

@@ -38,6 +38,11 @@ def _random_actor(n_sets, I, H, A, use_rnn, seed):
     (True, 128, 33, 8, 18, 5, False, True),      # use_rnn = False
     (False, 128, 1, 3, 30, 5, True, False),      # a single env, ragged tile
     (False, 128, 50, 4, 9, 20, False, False),    # the zoo's MaterialTransport mappo_ns: one MLP-layer network per agent (round 4: its weight stride)
+    (True, 128, 65, 4, 28, 5, True, True),       # input width exactly 32: the widest layer fc1 stages through LDS
+    (False, 64, 65, 3, 32, 7, True, False),      # ... per-agent weights, no agent id, two wavefronts per tile
+    (True, 64, 65, 4, 29, 5, True, True),        # input width 33: the first one fc1 reads straight from memory
+    (False, 128, 35, 2, 62, 3, True, True),      # input width 64: the widest supported
+    (True, 128, 35, 3, 1, 2, True, False),       # input width 1
 ])
 def test_fused_actor_matches_torch(shared, H, E, N, D, A, use_rnn, append):
     from marbler_amd.evaluate import BatchedActor
@@ -101,7 +106,7 @@ def _draw_actor_case(rng):
     return shared, H, E, N, D, A, use_rnn, append, pack
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(96))
 def test_fused_actor_random_shapes(seed):
     """Shapes nobody listed: every input width up to 64 (ragged fc1 rows, agent id on or off), 1 ... 32 actions (fc2's padded tile,
     the all-thread arg-max), ragged and tiny batches, shared / per-agent weights, GRU in all three weight forms / the MLP layer --

@@ -58,9 +58,9 @@ for E, H in ((4096, 128), (4096, 64), (1024, 128)):
     torch.cuda.synchronize()
     us = ev0.elapsed_time(ev1) * 1e3 / 50
     print(f"kernel {us:.1f} us per launch -> {(rel + life).max() / us / 1e3:.2f} ticks per ns if the launch is first start -> last end")
-    if "--fc1" in sys.argv:   # -DRG_ACTOR_STAMPS_FC1 build: slot 4 = fc1's operands arrived, slot 3 = its MFMAs done, slot 1 = fc1 + staging + barrier
-        print("   cumulative ticks: operands arrived %.0f, fc1 MFMAs done %.0f, Y / Hs written + barrier %.0f, GRU products %.0f, fc2 partials %.0f, end %.0f"
-              % tuple(raw[:, i].mean() for i in (4, 3, 1, 2, 5, 6)))
+    if "--fc1" in sys.argv:   # -DRG_ACTOR_STAMPS_FC1 build: the head of the wave in detail (slots 2..5, then slot 1 = behind the barrier)
+        print("   cumulative ticks: hidden loads issued %.0f, fc1 addresses done %.0f, fc1 products + bias arrived %.0f, Y / Hs written %.0f, barrier passed %.0f, end %.0f"
+              % tuple(raw[:, i].mean() for i in (2, 3, 4, 5, 1, 6)))
         continue
     raw[:, 0] = 0
     names = ["(where)", "fc1", "gru mfma", "gates", "hidden stored", "fc2", "argmax/q"]
