@@ -111,7 +111,7 @@ template <int H, bool SPLIT>   // SPLIT: the GRU's products on bfloat16 planes (
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256 registers (VGPR + AGPR): two tiles per CU, one's serial phases under the other's MFMAs
 __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
 #ifdef RG_ACTOR_STAMPS
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), rt_start = __builtin_amdgcn_s_memrealtime();
     int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     constexpr int NW = H / 32;  // wavefronts per tile
@@ -291,15 +291,15 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     constexpr int TPR = NTHREADS / TM, CPT = 32 / TPR;   // arg-max pass: TPR threads per tile row, CPT action columns each
     float b2v[CPT];
     auto request_fc2 = [&] {
+        // (unconditional loads from clamped rows, the padding columns are zeroed where they are used: a predicated load is a
+        // branch, and the compiler put a wait for the loads behind its join)
+        const int c2 = col < A ? col : 0;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            w2v[q4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (col < A) w2v[q4] = *reinterpret_cast<const float4 *>(W2 + static_cast<size_t>(col) * H + cb * 32 + half * 16 + 4 * q4);
-        }
+        for (int q4 = 0; q4 < 4; ++q4) w2v[q4] = *reinterpret_cast<const float4 *>(W2 + static_cast<size_t>(c2) * H + cb * 32 + half * 16 + 4 * q4);
 #pragma unroll
         for (int c_ = 0; c_ < CPT; ++c_) {
             const int c = (tid % TPR) * CPT + c_;
-            b2v[c_] = c < A ? B2[c] : 0.0f;
+            b2v[c_] = B2[c < A ? c : 0];
         }
     };
 
@@ -440,12 +440,16 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         {
             const int j = cb * 32 + col;
             floatx16 acc = zero16();
-            for (int kk = 0; kk < H / 2; kk += 4) {
-                const int k0 = half * (H / 2) + kk;
-                acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Y[swz4<H>(col, k0 >> 2)]),
-                            *reinterpret_cast<const float4 *>(Wih + static_cast<size_t>(j) * H + k0));
-            }
+            // the lane's half row of the layer, requested whole (H / 8 float4 = 16 or 8 registers quads) before the first product:
+            // asked for step by step, every four MFMAs waited a trip to L2
+            float4 wrow[H / 8];
+#pragma unroll
+            for (int q = 0; q < H / 8; ++q) wrow[q] = *reinterpret_cast<const float4 *>(Wih + static_cast<size_t>(j) * H + half * (H / 2) + 4 * q);
             const float b = Bih[j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < H / 8; ++q)
+                acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Y[swz4<H>(col, (half * (H / 2) + 4 * q) >> 2)]), wrow[q]);
             request_fc2();
 #pragma unroll
             for (int r = 0; r < 16; ++r) hn[r] = fmaxf(acc[r] + b, 0.0f);
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             const int k0 = cb * 32 + half * 16 + kk;
-            acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k0 >> 2)]), w2v[kk >> 2]);
+            acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Hs[swz4<H>(col, k0 >> 2)]), col < A ? w2v[kk >> 2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) Y[cb * (TM * 32) + crow(r) * 32 + col] = acc[r];  // Y is free again: NW partial tiles, row-major
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     }
 #ifdef RG_ACTOR_STAMPS
     RG_ASTAMP(6);
-    stamps[7] = static_cast<int>(t_start & 0x7FFFFFFF);   // absolute start (low bits): which waves ran side by side
+    stamps[7] = static_cast<int>(__builtin_amdgcn_s_memrealtime() - rt_start);   // the wave's life on the constant 100 MHz clock: slot 6 / slot 7 = shader clock / 100 MHz
     // slot 0: where the wave ran -- XCC_ID (hwreg 20) << 16 | HW_ID (hwreg 4: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
     stamps[0] = static_cast<int>((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 16) | (__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xFFFF));
     __syncthreads();
