@@ -105,10 +105,11 @@ class BatchedActor(object):
                                            self.n_actions, 1 if self.use_rnn else 0, packed)
         return self._ws
 
-    def forward_fused(self, obs, hidden, append_agent_id=True, restart=None, q_out=None, actions_out=None):
+    def forward_fused(self, obs, hidden, append_agent_id=True, restart=None, q_out=None, actions_out=None, stream=None):
         """One actor step for all E x N agents in one launch (rg_actor_forward: the matrix cores; GRU on bfloat16 planes unless pack_gru says otherwise).
         obs [E,N,D] f32; hidden [E,N,H] f32 updated IN PLACE; restart [E] uint8 (nonzero = start that
-        env's hidden state from zero) or None.  Returns (q [E,N,A], actions [E,N] int32)."""
+        env's hidden state from zero) or None; stream: a torch.cuda.Stream (default: the device's current stream).
+        Returns (q [E,N,A], actions [E,N] int32)."""
         import ctypes as C
         from . import _lib
         lib = _lib.load()
@@ -117,7 +118,8 @@ class BatchedActor(object):
             q_out = torch.empty(E, N, self.n_actions, device=obs.device)
         if actions_out is None:
             actions_out = torch.empty(E, N, dtype=torch.int32, device=obs.device)
-        stream = torch.cuda.current_stream(obs.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(obs.device)
         rc = lib.rg_actor_forward(C.byref(self._weights_struct()), E, N, obs.data_ptr(), D, 1 if append_agent_id else 0,
                                   restart.data_ptr() if restart is not None else None, hidden.data_ptr(),
                                   q_out.data_ptr(), actions_out.data_ptr(), C.c_void_p(stream.cuda_stream))
