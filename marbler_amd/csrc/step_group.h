@@ -362,6 +362,9 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 #ifdef RG_STAMPS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RG_STAMPS_CLOCK   // slot 5 = the wave's life on the constant 100 MHz clock: slot 6 / slot 5 = shader clock / 100 MHz
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
@@ -1388,6 +1391,9 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         }
         RG_STAMP(6);  // reset done
 #ifdef RG_STAMPS
+#ifdef RG_STAMPS_CLOCK
+        stamps[5] = static_cast<int>(__builtin_amdgcn_s_memrealtime() - rt_start);
+#endif
         if (lane == 0 && sv.io.qp_sweeps) {
             stamps[7] = max_sweeps;
             for (int i = 0; i < 8; ++i)

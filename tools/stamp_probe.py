@@ -35,6 +35,8 @@ for k in range(7):
     print(f"{names[k]:10s} cum {acc[k]:9.0f} ticks  delta {acc[k]-prev:9.0f}   (max cum over waves {mx[k]:9.0f})")
     prev = acc[k]
 print("mean max_sweeps of wave-leading env", float(acc[7]), "max", float(mx[7]))
+if os.environ.get("RG_STAMPS_CLOCK"):   # a -DRG_STAMPS_CLOCK build: slot 5 holds the wave's life in 100 MHz ticks
+    print(f"shader clock while the waves ran: {float(acc[6] / acc[5]) * 100:.0f} MHz (mean wave life {float(acc[6]):.0f} cycles = {float(acc[5]) / 100:.2f} us)")
 # the launch lasts as long as its slowest wave: distribution of the wave end stamps (slot 6) over the last launch
 end = (env.qp_sweeps.view(-1, 64)[:, 6] if TPE else env.qp_sweeps.view(-1, 8)[:, 6]).double().sort(descending=True).values
 print("last launch, wave end ticks: slowest %.0f, 4th %.0f, 16th %.0f, median %.0f, mean %.0f (%d waves)" %
