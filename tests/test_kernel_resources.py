@@ -138,6 +138,44 @@ def test_shipped_resources_lane_group(shipped):
             assert r["spill"] == 0 and r["scratch"] <= 128 and r["occupancy"] >= 3, (k, r)
 
 
+def test_shipped_actor_kernels_keep_their_weight_ring_and_two_tiles_per_cu():
+    """csrc/actor_mfma.hip streams the GRU's weights through a ring of groups ahead of the MFMAs.  Round 4 found that the ring
+    had never existed in the ISA: the scheduler sank every load to just above its first use (`s_waitcnt vmcnt(0..3)` before
+    each group), and nothing failed -- the kernel was only slower.  Scheduling fences hold the loads now; this looks at the
+    SHIPPED kernels: inside the bfloat16 MFMA stream every wait on the vector-memory counter leaves at least two groups
+    (6 loads) in flight, except the four that drain the ring at the end.  And the register count that decides whether two
+    tiles share a CU (256 per lane, no scratch)."""
+    import sys
+    import tempfile
+    from marbler_amd import build as hip_build
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_scan
+    if not os.path.exists(hip_build.LIB):
+        pytest.skip("librobogym_hip.so is not built")
+    seen = 0
+    with tempfile.TemporaryDirectory() as d:
+        try:
+            objs = isa_scan.extract_code_objects(hip_build.LIB, d)
+        except RuntimeError as exc:
+            pytest.skip(str(exc))
+        for co in objs:
+            res = isa_scan.resources(co)
+            for name, insts in isa_scan.disassemble(co).items():
+                if "actor_kernel" not in name:
+                    continue
+                r = res[name]
+                assert r["vgpr"] + r["agpr"] <= 256 and r["scratch"] == 0 and r["lds"] <= 32 * 1024, (name, r)
+                if "ELb1E" not in name:      # the float32-MFMA form has its own (older) pipeline
+                    continue
+                seen += 1
+                idx = [i for i, it in enumerate(insts) if it.op.startswith("v_mfma_f32_32x32x16")]
+                assert len(idx) in (144, 288), (name, len(idx))     # H / 16 k-steps x 3 gates x 2 matrices x 6 plane products
+                waits = [int(m.group(1)) for it in insts[idx[0]:idx[-1]] if it.op == "s_waitcnt"
+                         for m in [re.search(r"vmcnt\((\d+)\)", it.args)] if m]
+                assert len(waits) >= 20 and sorted(waits)[4] >= 6, (name, waits)
+    assert seen == 2
+
+
 def test_exec_prologue_check_on_real_compiler_output(tmp_path):
     """The detector on what THIS compiler emits for the instantiation ROCm 7.2 miscompiled (tools/n7_bisect/tpe_probe.hip:
     MaterialTransport, N = 7): clean with the flags that always passed, one finding with `-O3 -fno-slp-vectorize` -- the block
