@@ -43,7 +43,7 @@ class GymmaVecEnv(object):
         enable_time_limit): step() is ONE launch.  fused=False composes them from torch ops around the step (a dozen
         launches; kept as the readable statement of the contract and as the check of the fused path).
         alias_outputs: step() returns the env's persistent output buffers themselves (reward sum, terminated,
-        TimeLimit.truncated) instead of copies -- three small copy launches less per step, but the NEXT step overwrites
+        TimeLimit.truncated) instead of copies -- one small copy launch less per step, but the NEXT step overwrites
         what the previous one returned; only for callers that consume a step's outputs before stepping again."""
         self.fused = bool(fused)
         self.alias_outputs = bool(alias_outputs)
@@ -86,8 +86,8 @@ class GymmaVecEnv(object):
             if self.alias_outputs:
                 out["TimeLimit.truncated"] = self.env.truncated
                 return self.env.reward_sum, self.env.ended, out
-            out["TimeLimit.truncated"] = self.env.truncated.clone()
-            return self.env.reward_sum.clone(), self.env.ended.clone(), out
+            reward_sum, ended, out["TimeLimit.truncated"] = self.env.gymma_outputs_copy()   # one copy launch for the three
+            return reward_sum, ended, out
         self._elapsed += 1
         truncated = (self._elapsed >= self.episode_limit) & ~done          # gym TimeLimit
         ended = done | truncated

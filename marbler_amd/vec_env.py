@@ -232,13 +232,25 @@ class VecRobotariumEnv(object):
         if self.time_limit < 1:
             raise ValueError("time_limit must be > 0")
         self.elapsed = self._alloc((E,), torch.int32)
-        self._trunc_u8 = self._alloc((E,), torch.uint8)
-        self._ended_u8 = self._alloc((E,), torch.uint8)
+        # the three per-step outputs of the block are views of ONE allocation [reward_sum f32 | ended u8 | truncated u8], so
+        # that a consumer who must keep a step's outputs copies them with one launch (gymma_outputs_copy)
+        pad = (E + 15) // 16 * 16
+        self._gymma_arena = self._alloc((4 * pad + 2 * pad,), torch.uint8)
+        self._gymma_pad = pad
+        self.reward_sum, self._ended_u8, self._trunc_u8 = self._gymma_views(self._gymma_arena)
         self.truncated, self.ended = self._trunc_u8.view(torch.bool), self._ended_u8.view(torch.bool)
-        self.reward_sum = self._alloc((E,), torch.float32)
         self._io.elapsed, self._io.truncated = self.elapsed.data_ptr(), self._trunc_u8.data_ptr()
         self._io.ended, self._io.reward_sum = self._ended_u8.data_ptr(), self.reward_sum.data_ptr()
         self._io.time_limit = self.time_limit
+
+    def _gymma_views(self, arena):
+        E, pad = self.E, self._gymma_pad
+        return arena[:4 * E].view(torch.float32), arena[4 * pad:4 * pad + E], arena[5 * pad:5 * pad + E]
+
+    def gymma_outputs_copy(self):
+        """(reward_sum [E] f32, ended [E] bool, truncated [E] bool) of the last step as FRESH tensors: one copy launch."""
+        r, e, t = self._gymma_views(self._gymma_arena.clone())
+        return r, e.view(torch.bool), t.view(torch.bool)
 
     def step(self, actions):
         """actions: int tensor [E,N] on the device (int32 is used as is; other int dtypes are
