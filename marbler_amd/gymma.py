@@ -246,6 +246,8 @@ class BatchedRunner(object):
         self.gen.manual_seed(int(seed))
         self.hidden = actor.init_hidden(venv.E).to(dev)
         self._restart = torch.ones(venv.E, dtype=torch.uint8, device=dev)
+        self._q = torch.empty(venv.E, venv.n_agents, venv.n_actions, device=dev)
+        self._zero = torch.zeros((), device=dev)
         venv.reset()
 
     @torch.no_grad()
@@ -259,14 +261,23 @@ class BatchedRunner(object):
                "episode_start": torch.empty(T, E, dtype=torch.bool, device=dev)}
         fused = self.actor.fused_supported()
         eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
+        # With the fused step (one launch: env step + TimeLimit + reductions) and the fused actor, a time step is seven
+        # launches: the three outputs are written where EPyMARL wants them (no intermediate tensors), the actor reads the
+        # episode-end flags of the previous step in place and writes its greedy actions into the batch.
+        direct = fused and v.fused
         for t in range(T):
-            obs = v.get_obs()                      # zeros right after a reset, like the reference's reset()
-            out["obs"][t] = obs
-            out["state"][t] = v.get_state()
-            out["episode_start"][t] = self._restart.bool()
+            if direct and v._obs is None:          # the next observation of an env that just ended is its reset observation (zeros)
+                torch.where(env.ended[:, None, None], self._zero, env.obs, out=out["obs"][t])
+                obs = v._obs = out["obs"][t]
+            else:
+                obs = v.get_obs()                  # zeros right after a reset, like the reference's reset()
+                out["obs"][t] = obs
+            out["state"][t] = obs.reshape(E, N * D)
+            out["episode_start"][t] = self._restart.view(torch.bool)
             if fused:
+                greedy = out["actions"][t] if self.epsilon <= 0.0 else None
                 _, greedy = self.actor.forward_fused(obs.contiguous(), self.hidden, append_agent_id=self.obs_agent_id,
-                                                     restart=self._restart)
+                                                     restart=self._restart, q_out=self._q, actions_out=greedy)
             else:
                 h_in = torch.where(self._restart.bool()[:, None, None], torch.zeros_like(self.hidden), self.hidden)
                 q, h = self.actor.forward(torch.cat([obs, eye], dim=2) if self.obs_agent_id else obs, h_in)
@@ -275,14 +286,20 @@ class BatchedRunner(object):
             if self.epsilon > 0.0:
                 explore = torch.rand(E, N, generator=self.gen, device=dev) < self.epsilon
                 rnd = torch.randint(0, A, (E, N), generator=self.gen, device=dev, dtype=torch.int32)
-                actions = torch.where(explore, rnd, greedy)
+                torch.where(explore, rnd, greedy, out=out["actions"][t])
+            elif not fused:
+                out["actions"][t] = greedy
+            if direct:
+                env.step(out["actions"][t])
+                v._obs, v._ended = None, env.ended
+                out["reward"][t] = env.reward_sum
+                out["terminated"][t] = env.ended
+                self._restart = env._ended_u8      # read by the next actor launch, before the next env step rewrites it
             else:
-                actions = greedy
-            out["actions"][t] = actions
-            reward, ended, _ = v.step(actions.contiguous())
-            out["reward"][t] = reward
-            out["terminated"][t] = ended
-            self._restart.copy_(ended)
+                reward, ended, _ = v.step(out["actions"][t])
+                out["reward"][t] = reward
+                out["terminated"][t] = ended
+                self._restart.copy_(ended)
         out["obs"][T] = v.get_obs()
         out["state"][T] = v.get_state()
         return out
