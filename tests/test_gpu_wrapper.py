@@ -140,6 +140,33 @@ def test_batched_runner_collects_transitions():
     assert torch.equal(b2["episode_start"][0], b["terminated"][-1])
 
 
+@pytest.mark.parametrize("epsilon", [0.0, 0.25])
+def test_batched_runner_in_place_path_equals_the_composed_one(epsilon):
+    """BatchedRunner writes a fused GymmaVecEnv's outputs straight into the transition batch (seven launches per time step);
+    over a composed one (fused=False: gym's TimeLimit and the reductions as torch ops around the step) it goes through
+    step() / get_obs().  Same envs, same actor, same exploration stream: the batches must be equal, element for element
+    (a short time limit, so that truncations happen)."""
+    import torch
+    from marbler_amd.evaluate import BatchedActor
+    from marbler_amd.gymma import BatchedRunner, GymmaVecEnv
+    from test_gpu_actor import _random_actor
+    E, T = 96, 70
+    batches = []
+    for fused in (True, False):
+        v = GymmaVecEnv("robotarium_gym:PredatorCapturePrey-v0", E, time_limit=25, seed=5, fused=fused)
+        actor = BatchedActor(_random_actor(1, v.obs_size + v.n_agents, 64, v.n_actions, True, seed=4), v.n_agents, device=v.env.device)
+        runner = BatchedRunner(v, actor, epsilon=epsilon, seed=9)
+        b = runner.run(T)
+        b2 = runner.run(7)       # a second call continues the same episodes
+        batches.append((b, b2, int(v.env.done_count.sum())))
+        v.env.close()
+    (a, a2, na), (c, c2, nc) = batches
+    assert na == nc and int(a["terminated"].sum()) > E
+    for x, y in ((a, c), (a2, c2)):
+        for key in ("obs", "state", "actions", "reward", "terminated", "episode_start", "avail_actions"):
+            assert torch.equal(x[key], y[key]), key
+
+
 @pytest.mark.parametrize("name", ["pcp_n5", "warehouse_n8", "mt_n6", "viol_PredatorCapturePrey_collision"])
 def test_gymma_env_reduces_the_reference_vectors_like_epymarl(name):
     """GymmaEnv (EPyMARL's gymma contract: float(sum(reward_n)), all(done_n), padded per-agent observations,
