@@ -62,3 +62,61 @@ extern "C" int run_mode(int mode, int active, float *out, long long *cyc) {
     }
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------ packed f32 against scalar f32 (round 5)
+// Does `v_pk_fma_f32` (two binary32 fmas per lane per instruction, even-aligned register pairs) issue faster than the two
+// `v_fma_f32` it replaces?  INDEPENDENT streams (8 accumulator pairs per wave, no instruction depends on the one before it),
+// 1 / 2 / 4 waves per SIMD (one workgroup of 4 / 8 / 16 waves on one CU), every wave timed with s_memtime; the driver
+// (issue.py --pk) reports flop / clk / SIMD = waves_per_simd x instructions x 64 lanes x flops per lane-instruction / cycles.
+// MODE 0: 16 x v_fma_f32 per trip (2 flop per lane each);  MODE 1: 8 x v_pk_fma_f32 per trip (4 flop per lane each): the
+// SAME arithmetic per trip;  MODE 2 / 3: v_mul_f32 + v_add_f32 pairs against v_pk_mul_f32 + v_pk_add_f32 (the unfused form
+// the -ffp-contract=off step kernels consist of).
+typedef float pkf2 __attribute__((ext_vector_type(2)));
+constexpr int PK_REP = 256;
+template <int MODE>
+__global__ __launch_bounds__(1024) void bench_pk(float *out, long long *cyc) {
+    pkf2 a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = pkf2{threadIdx.x * 1e-3f + i, threadIdx.x * 2e-3f - i};
+    const pkf2 m = {0.999f, 1.001f}, c = {1e-3f, -1e-3f};
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    for (int i = 0; i < PK_REP; ++i) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_fma_f32 %0, %0, %2, %4\n\tv_fma_f32 %1, %1, %3, %5" : "+v"(a[j].x), "+v"(a[j].y) : "v"(m.x), "v"(m.y), "v"(c.x), "v"(c.y));
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(m), "v"(c));
+        } else if constexpr (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asm volatile("v_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5"
+                             : "+v"(a[j].x), "+v"(a[j].y) : "v"(m.x), "v"(m.y), "v"(c.x), "v"(c.y));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("v_pk_mul_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %2" : "+v"(a[j]) : "v"(m), "v"(c));
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y;
+    out[threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+// waves_per_simd in {1, 2, 4}: one workgroup of 4 x that many waves (a CU has 4 SIMDs); cyc[w] = ticks of wave w
+extern "C" int run_pk(int mode, int waves_per_simd, float *out, long long *cyc) {
+    const int threads = 256 * waves_per_simd;
+    switch (mode) {
+        case 0: bench_pk<0><<<1, threads>>>(out, cyc); break;
+        case 1: bench_pk<1><<<1, threads>>>(out, cyc); break;
+        case 2: bench_pk<2><<<1, threads>>>(out, cyc); break;
+        case 3: bench_pk<3><<<1, threads>>>(out, cyc); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
