@@ -16,7 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librobogym_hip.so")
 SOURCES = ["robogym_kernels.hip", "robogym_rollout_group.hip", "robogym_tpe.hip", "robogym_rollout_tpe.hip", "robogym_capi.hip",
            "actor_mfma.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("sim_math.h", "kernel_args.h", "device_common.h", "step_group.h", "step_tpe.h")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("sim_math.h", "kernel_args.h", "device_common.h", "step_group.h", "step_tpe.h", "ipm_qp.h", os.path.join("probes", "diag.h"))
+                                           if os.path.exists(os.path.join(CSRC, h))] + \
           [os.path.join(HERE, "..", "include", "robogym.h")]
 ARCH = "gfx950"
 # Per-file flags (results are bit-identical either way: the same IEEE operations; tools/ab_job.sh measured them).
@@ -76,11 +77,15 @@ def build(force=False, verbose=False, defines=(), out=None):
     library is always built with the flags above."""
     extra = os.environ.get("RG_EXTRA_HIPCC_FLAGS", "").split()
     no_file_flags = bool(os.environ.get("RG_NO_FILE_FLAGS"))
-    if out is None and (extra or no_file_flags):
-        raise RuntimeError("RG_EXTRA_HIPCC_FLAGS / RG_NO_FILE_FLAGS are for diagnostic variants (build(out=...)): "
-                           "the shipped library's flags are fixed in marbler_amd/build.py")
-    if out is None and not force and not needs_build():
-        return LIB
+    if out is None:
+        if not force and not needs_build():
+            return LIB
+        if extra or no_file_flags:
+            # a shell that still exports an A/B flag must not change (or block) the shipped build: its flags are fixed above
+            import warnings
+            warnings.warn("RG_EXTRA_HIPCC_FLAGS / RG_NO_FILE_FLAGS are for diagnostic variants (build(out=...)) and are IGNORED for the "
+                          "shipped library, whose flags are fixed in marbler_amd/build.py")
+            extra, no_file_flags = [], False
     shipped = out is None
     out = out or LIB
     # one object per translation unit, compiled side by side (the kernel instantiations dominate:

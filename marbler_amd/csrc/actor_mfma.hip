@@ -497,7 +497,9 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         const int i = tid / TPR, sub = tid % TPR;
         const bool ok = row_ok(i);
         const int r = ok ? row_of(i) : 0;
-        float best = -3.0e38f;
+        // torch.argmax's answer on every row, non-finite ones included: the first maximum, a NaN counting as the largest value
+        // (the first NaN wins); a row of -inf only keeps the sentinel and is given column 0 below.  The index is always in [0, A).
+        float best = -__builtin_huge_valf();
         int arg = 0x7FFFFFFF;
 #pragma unroll
         for (int c_ = 0; c_ < CPT; ++c_) {
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 for (int wv = 0; wv < NW; ++wv) v = v + Y[wv * (TM * 32) + i * 32 + c];
                 v = v + b2v[c_];
                 if (ok && a.q) a.q[static_cast<size_t>(r) * A + c] = v;
-                if (v > best) {  // first maximum, like torch.argmax
+                if (v > best || (v != v && best == best)) {  // first maximum, like torch.argmax
                     best = v;
                     arg = c;
                 }
@@ -518,11 +520,13 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         for (int d = 1; d < TPR; d <<= 1) {   // the TPR threads of a row are neighbouring lanes
             const float ob = __shfl_xor(best, d);
             const int oa = __shfl_xor(arg, d);
-            if (ob > best || (ob == best && oa < arg)) {
+            const bool on = ob != ob, bn = best != best;
+            if (ob > best || (on && !bn) || ((ob == best || (on && bn)) && oa < arg)) {
                 best = ob;
                 arg = oa;
             }
         }
+        arg = static_cast<unsigned>(arg) >= static_cast<unsigned>(A) ? 0 : arg;
         if (ok && sub == 0 && a.actions) a.actions[r] = arg;
     }
     {

@@ -24,9 +24,6 @@ constexpr int MAX_DRAWS = 128;  // u32 draws per reset: 4 + 2N + P <= 4 + 32 + 6
 // Instead XCD x works through ONE contiguous run of chunks, so shared lines meet in one L2 (measured with
 // rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/).  Affinity only: results do not depend on the block -> XCD map.
 __device__ __forceinline__ int xcd_chunk(int G = gridDim.x) {
-#ifdef RG_NO_XCD_REMAP  // diagnostic builds (A/B traffic measurements)
-    return blockIdx.x;
-#endif
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int q = G >> 3, r = G & 7;

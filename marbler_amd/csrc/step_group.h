@@ -29,30 +29,18 @@
 #include <type_traits>
 
 #include "device_common.h"
+#include "probes/diag.h"   // diagnostic hooks: every RG_* macro below expands to nothing in the shipped build
 
 namespace rg {
 
-// Output stores (observation rows, rewards, distances): -DRG_NT_STORES issues them as non-temporal (streaming) stores --
-// an experiment on the end-of-launch write-back; the shipped build uses plain stores.
-typedef float rg_f4v __attribute__((ext_vector_type(4)));
+// Output stores (observation rows, rewards, distances): plain stores (non-temporal ones were tried: NOTEBOOK.md section 4.4)
 __device__ __forceinline__ void out_store4(float *p, float a, float b, float c, float d) {
-#ifdef RG_NT_STORES
-    __builtin_nontemporal_store(rg_f4v{a, b, c, d}, reinterpret_cast<rg_f4v *>(p));
-#else
     *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
-#endif
 }
 __device__ __forceinline__ void out_store1(float *p, float a) {
-#ifdef RG_NT_STORES
-    __builtin_nontemporal_store(a, p);
-#else
     *p = a;
-#endif
 }
 
-#ifndef RG_CHUNK
-#define RG_CHUNK 5
-#endif
 // sub-steps validated together (ILP across independent test chains).  The controller periods of the
 // reference's configurations are 15 and 14 sub-steps: three chunks of 5, or two and a remainder chunk of 4.
 constexpr int CHUNK = RG_CHUNK;
@@ -61,36 +49,12 @@ static_assert(CHUNK >= 1 && CHUNK <= 5, "the sparse collision pre-test covers su
 // ------------------------------------------------------------------ controller (a3..a8)
 // utilities/controller.py:20-24 over the restated rps closures,
 // followed by Robotarium.set_velocities' clipping.  Called in wave-uniform control flow.
-#ifdef RG_STAMPS_CTRL  // diagnostic (-DRG_STAMPS -DRG_STAMPS_CTRL): ticks per controller part, summed over the step's controllers
-#define RG_CTRL_TICK(i)                                                     \
-    {                                                                       \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
-        ctrl_ticks[i] += static_cast<int>(t_ - ctrl_t);                     \
-        ctrl_t = t_;                                                        \
-    }
-#else
-#define RG_CTRL_TICK(i)
-#endif
 template <int GW>
 __device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, int N, int ag, bool lane_ok,
                                           bool upd, float x, float y, float c, float s, float gx, float gy, float &v,
-                                          float &w, int *ctrl_ticks = nullptr) {
-#ifdef RG_STAMPS_CTRL
-    asm volatile("" ::"v"(x), "v"(y), "v"(c), "v"(s));
-    unsigned long long ctrl_t = __builtin_amdgcn_s_memtime();
-#endif
+                                          float &w RG_CTRL_TICKS_PARAM) {
+    RG_CTRL_BEGIN(x, y, c, s)
     // a4 uni_to_si_states, a5 si_position_controller (gain 1, |dxi| <= 0.15)
-#ifdef RG_SHADOW_POS
-    {
-        float ax = gx - (x + k.pd * s), ay = gy - (y + k.pd * c);
-        const float nrm = norm2_spec(ax, ay);
-        const float sc = k.pvl / nrm;
-        const bool clip = nrm > k.pvl;
-        ax = clip ? ax * sc : ax;
-        ay = clip ? ay * sc : ay;
-        asm volatile("" ::"v"(ax), "v"(ay));
-    }
-#endif
     const float xix = x + k.pd * c, xiy = y + k.pd * s;
     float ux = gx - xix, uy = gy - xiy;
     {
@@ -128,27 +92,7 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         emax[K - 1] = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
         mu[K - 1] = dmu[K - 1] = 0.0f;
     });
-#ifdef RG_STAMPS_CTRL
-#pragma unroll
-    for (int r_ = 0; r_ < GW - 1; ++r_) asm volatile("" ::"v"(fx[r_]), "v"(bp[r_]), "v"(emax[r_]));
-#endif
-#ifdef RG_PROBE_SETUP_TWICE  // probe: what the pair constants cost (a shadow copy of the block above; results discarded)
-    static_for<1, GW>([&](auto KK) {
-        constexpr int K = decltype(KK)::value;
-        float pxi = xor_lane<K>(xiy), pyi = xor_lane<K>(xix);
-        asm volatile("" : "+v"(pxi), "+v"(pyi));
-        const float dx = xix - pxi, dy = xiy - pyi;
-        const float ee = dx * dx + dy * dy;
-        const float h = ee - k.r2;
-        const float gain = ((h >= 0.0f) | !has_unsafe) ? bgain : ugain;
-        const float b = gain * ((h * h) * h);
-        const float n2 = 2.0f * ee;
-        const bool ok = lane_ok & ((ag ^ K) < N) & (n2 > 0.0f);
-        const float rn2 = ok ? 1.0f / n2 : 0.0f;
-        float q0 = dx * rn2, q1 = dy * rn2, q2 = (0.5f * b) * rn2, q3 = ok ? fmaxf(__builtin_fabsf(dx), __builtin_fabsf(dy)) : 0.0f;
-        asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));
-    });
-#endif
+    RG_CTRL_PIN_ROUNDS(GW, fx, bp, emax)
     RG_CTRL_TICK(0);  // position controller + pair constants
     {   // "Threshold control inputs before QP": decided on squares; never taken after the 0.15 clip
         const float n2u = ux * ux + uy * uy;
@@ -200,13 +144,6 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
             const float gchg = group_max_nonneg<GW>(chg);
             const float gum = fmaxf(k.bml, group_max_nonneg<GW>(um));
             active = (gchg > qp_rtol * gum) & (sweeps < qp_cap);
-#ifdef RG_SHADOW_CONV  // probes (shadow copies, results discarded): what a block costs on the launch's critical path
-            {
-                float g2 = group_max_nonneg<GW>(chg * 1.5f), g3 = fmaxf(k.bml, group_max_nonneg<GW>(um * 1.5f));
-                bool a2 = (g2 > qp_rtol * g3) & (sweeps < qp_cap);
-                asm volatile("" ::"s"(__ballot(a2)));
-            }
-#endif
             if constexpr (PHASE == 3) {
                 if (active) {  // restart: the multipliers extrapolated along their last change, u rebuilt from them
                     const float ga = group_sum<GW>(pa), gb = group_sum<GW>(pb);
@@ -236,9 +173,7 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         if (!__any(active)) break;
         sweep(std::integral_constant<int, 0>{});
     }
-#ifdef RG_STAMPS_CTRL
-    asm volatile("" ::"v"(ux), "v"(uy));
-#endif
+    RG_CTRL_PIN2(ux, uy);
     RG_CTRL_TICK(1);  // sweeps
     // a7 si_to_uni_dyn, a8 set_velocities
     float vv = c * ux + s * uy;
@@ -251,10 +186,8 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
     ww = ww < -k.wmax ? -k.wmax : ww;
     v = upd ? vv : v;
     w = upd ? ww : w;
-#ifdef RG_STAMPS_CTRL
-    asm volatile("" ::"v"(v), "v"(w));
-    ctrl_ticks[3] += sweeps;
-#endif
+    RG_CTRL_PIN2(v, w);
+    RG_CTRL_COUNT_SWEEPS(sweeps);
     RG_CTRL_TICK(2);  // si -> uni, clips
     return my_sweeps;
 }
@@ -333,21 +266,6 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
     });
 }
 
-// Diagnostic build only (-DRG_STAMPS, tools/stamp_probe.py): wave-cycle stamps of the step's
-// phases, written over io.qp_sweeps of the wave's first 8 envs.  No stamp executes in the
-// shipped library.
-#if defined(RG_STAMPS) && defined(RG_STAMPS_EPI)  // slots 0..2 mark points inside the PCP epilogue instead
-#define RG_STAMP(i) \
-    if ((i) > 2) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
-#define RG_STAMP_E(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
-#elif defined(RG_STAMPS)
-#define RG_STAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
-#define RG_STAMP_E(i)
-#else
-#define RG_STAMP(i)
-#define RG_STAMP_E(i)
-#endif
-
 // ------------------------------------------------------------------ the step kernel
 // NT: the agent count when it is a compile-time constant (instantiated for GW = 8: 5..8), 0 = read
 // it from the parameter block.  One env step of the wave's envs; `sv` = this step's slice of the
@@ -359,13 +277,7 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
 template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD, bool GYM>
 __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, const StepView &sv) {
     constexpr int EPW = WAVE / GW;  // envs per wave
-#ifdef RG_STAMPS
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef RG_STAMPS_CLOCK   // slot 5 = the wave's life on the constant 100 MHz clock: slot 6 / slot 5 = shader clock / 100 MHz
-    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
-#endif
-#endif
+    RG_STAMPS_BEGIN()
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
     // ---- kernel arguments first: every pointer and scalar the loads below need, fetched TOGETHER.  Left to itself
@@ -569,9 +481,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
     bool replayed = false;  // wave-uniform: some chunk of this step went through the exact-test replay
     float dist = 0.0f;
     if constexpr (!OBS_ONLY) {
-#ifdef RG_STAMPS
-        asm volatile("" ::"v"(x), "v"(y), "v"(th), "v"(carry), "v"(act));
-#endif
+        RG_PIN5(x, y, th, carry, act);
         RG_STAMP(0);  // inputs loaded
         // ---- a1 goal generation (agent.py:48-76, warehouse.py:19-45, MaterialTransport.py:19-46)
         float gx = x, gy = y;
@@ -606,12 +516,8 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
         const int ghost_q = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(1000.0f + 32.0f * ag, -1000.0f));
         float v = 0.0f, w = 0.0f, s = 0.0f, c = 1.0f;
-#ifdef RG_STAMPS_CHUNK
-        int chunk_ticks[4] = {0, 0, 0, 0};  // ticks in the dense pre-test, ticks in the replay, dense chunks, replayed chunks
-#endif
-#ifdef RG_STAMPS_CTRL
-        int ctrl_ticks[5] = {0, 0, 0, 0, 0};  // set-up, sweeps, tail, wave-level sweep count, heading sin/cos
-#endif
+        RG_CHUNK_LOCALS()
+        RG_CTRL_LOCALS()
         float acc = carry, last = 0.0f;  // dist incl. the pending sub-step; length of the last sub-step
         bool dead = false;               // group-uniform: the env hit a violation (roboEnv.py:92-94)
         float fin_x = 0.0f, fin_y = 0.0f;
@@ -620,31 +526,11 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         // roundings of the 29..74 Euler updates do not pile up in x, y (float spec, oracle/oracle_core.h)
         float bx = x, by = y, ox = 0.0f, oy = 0.0f;
         const bool penalize = p.penalize_violations != 0;
-#ifdef RG_FIXED_U  // probe build only (tools/perf_probe.py --set headline): the sub-step counts as compile-time constants (29 / 15:
-        const int U = RG_FIXED_U, period = 15;  // PredatorCapturePrey, Warehouse, Simple) -- what the loop bookkeeping is worth
-#else
         const int U = p.update_frequency, period = p.controller_period;
-#endif
         for (int it0 = 0; it0 < U; it0 += period) {
             const int n = (U - it0) < period ? (U - it0) : period;
-#ifdef RG_STAMPS_CTRL
-            asm volatile("" ::"v"(th));
-            const unsigned long long t_sc = __builtin_amdgcn_s_memtime();
-            sincos_spec(th, s, c);
-            asm volatile("" ::"v"(s), "v"(c));
-            ctrl_ticks[4] += static_cast<int>(__builtin_amdgcn_s_memtime() - t_sc);
-            const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w, ctrl_ticks);
-#else
-            sincos_spec(th, s, c);
-            const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w);
-#ifdef RG_SHADOW_SINCOS
-            {
-                float s2, c2;
-                sincos_spec(th * 1.0001f, s2, c2);
-                asm volatile("" ::"v"(s2), "v"(c2));
-            }
-#endif
-#endif
+            RG_HEADING_SINCOS(th, s, c);
+            const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w RG_CTRL_TICKS_ARG);
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
             const float dtv = k.dt * v, dtw = k.dt * w;
             float sd, cd;
@@ -718,9 +604,6 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                         static_for<1, GW>([&](auto KK) { d[decltype(KK)::value - 1] = diff(xor_lane_i<decltype(KK)::value>(qv)); });
                     }
                     int dm = 0x7FFFFFFF;
-#ifdef RG_PROBE_NO_PAIRTEST  // probe build only (WRONG results: collisions go unseen): the launch without the pair pre-test,
-                    return dm;  // an upper bound on what any cheaper collision pre-test could save (tools/perf_probe.py --set pairtest)
-#endif
                     dot2_batch<R>(d);
 #pragma unroll
                     for (int r = 0; r < R; ++r) dm = d[r] < dm ? d[r] : dm;
@@ -735,12 +618,6 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                     constexpr int SPAN0 = C - 1 < 2 ? C - 1 : 2;
                     const int t0 = SPAN0 == 0 ? thr_pre : SPAN0 == 1 ? thr_s1 : thr_s2;
                     dmin_u[0] = pair_min(q[0]);
-#ifdef RG_SHADOW_PAIRMIN
-                    {
-                        int d2_ = pair_min(q[C > 1 ? 1 : 0]);
-                        asm volatile("" ::"v"(d2_));
-                    }
-#endif
                     sparse_hit = sparse_hit | (dmin_u[0] <= t0);
                     if constexpr (C >= 4) {
                         const int t3 = C == 4 ? thr_pre : thr_s1;
@@ -748,25 +625,15 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                         sparse_hit = sparse_hit | (dmin_u[3] <= t3);
                     }
                 }
-#ifdef RG_DENSE_PRETEST  // diagnostic build: every chunk takes the dense pre-test (A/B runs against rounds 1-2)
-                sparse_hit = live;
-#endif
                 if (penalize && __any(sparse_hit | bnd_any)) {
-#ifdef RG_STAMPS_CHUNK  // diagnostic: ticks inside the dense pre-test (slot 0) and inside the exact replay (slot 1), summed over the step
-                const unsigned long long t_dense0 = __builtin_amdgcn_s_memtime();
-#endif
+                RG_CHUNK_DENSE_BEGIN()
                 static_for<1, C>([&](auto UU) {
                     constexpr int u = decltype(UU)::value;
                     if constexpr (u != 3) dmin_u[u] = pair_min(q[u]);
                 });
                 int dmin = dmin_u[0];
                 static_for<1, C>([&](auto UU) { dmin = dmin_u[decltype(UU)::value] < dmin ? dmin_u[decltype(UU)::value] : dmin; });
-#ifdef RG_STAMPS_CHUNK
-                asm volatile("" ::"v"(dmin));
-                const unsigned long long t_dense1 = __builtin_amdgcn_s_memtime();
-                chunk_ticks[0] += static_cast<int>(t_dense1 - t_dense0);
-                chunk_ticks[2] += 1;
-#endif
+                RG_CHUNK_DENSE_END(dmin)
                 if (__any((dmin <= thr_pre) | bnd_any)) {
                     replayed = true;
                     // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94): the
@@ -818,11 +685,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                         rc = cn;
                         rs = sn;
                     });
-#ifdef RG_STAMPS_CHUNK
-                    asm volatile("" ::"v"(rx), "v"(ry));
-                    chunk_ticks[1] += static_cast<int>(__builtin_amdgcn_s_memtime() - t_dense1);
-                    chunk_ticks[3] += 1;
-#endif
+                    RG_CHUNK_REPLAY_END(rx, ry)
                 }
                 }
             };
@@ -856,17 +719,8 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         dist = viol ? acc : acc - last;
         carry = last;
         RG_STAMP(3);  // all periods done
-#ifdef RG_STAMPS_CTRL
-        stamps[0] = ctrl_ticks[0];
-        stamps[1] = ctrl_ticks[1];
-        stamps[2] = ctrl_ticks[2] * 100 + ctrl_ticks[3];   // tail ticks x 100 + sweeps the wave executed
-        stamps[3] = ctrl_ticks[4];
-#endif
-#ifdef RG_STAMPS_CHUNK
-        stamps[0] = chunk_ticks[0];
-        stamps[1] = chunk_ticks[1];
-        stamps[2] = chunk_ticks[2] * 1000 + chunk_ticks[3];
-#endif
+        RG_CTRL_REPORT()
+        RG_CHUNK_REPORT()
     }
 
     // ---- scenario epilogue
@@ -1023,10 +877,6 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         } else {
             if (lane_ok) out_store4(obs_row, x, y, qx, qy);
             write_neighbour_obs<GW, 4, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
-#ifdef RG_SHADOW_KNN
-            asm volatile("" ::: "memory");
-            write_neighbour_obs<GW, 4, NT>(lds, N, p.num_neighbors, ag, gbase, lane_ok, x, y, obs_row);
-#endif
         }
         RG_STAMP_E(1);  // observations written
         if constexpr (!OBS_ONLY) {  // a14 reward / termination (PredatorCapturePrey.py:155-176, 209-216)
@@ -1390,16 +1240,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
             if (need && ag == 0) a.st.next_episode[e] = rc_raw;
         }
         RG_STAMP(6);  // reset done
-#ifdef RG_STAMPS
-#ifdef RG_STAMPS_CLOCK
-        stamps[5] = static_cast<int>(__builtin_amdgcn_s_memrealtime() - rt_start);
-#endif
-        if (lane == 0 && sv.io.qp_sweeps) {
-            stamps[7] = max_sweeps;
-            for (int i = 0; i < 8; ++i)
-                if (chunk * EPW + i < a.E) sv.io.qp_sweeps[chunk * EPW + i] = stamps[i];
-        }
-#endif
+        RG_STAMPS_WRITE(lane, sv.io.qp_sweeps, chunk * EPW, a.E, max_sweeps)
     }
 }
 
@@ -1464,13 +1305,10 @@ static hipError_t launch_step_scn(const KernelArgs &a_in, hipStream_t stream) {
     // time is the maximum over its envs (QP sweeps, replays, resets), and the idle SIMDs are free.
     KernelArgs a = a_in;
     int epw = WAVE / gw;
-#ifndef RG_STAMPS
-#ifndef RG_MAX_WAVES
-#define RG_MAX_WAVES 1024
-#endif
-    while (epw >= 2 && (a.E + epw / 2 - 1) / (epw / 2) <= RG_MAX_WAVES) epw /= 2;
-    a.envs_per_wave = epw;
-#endif
+    if constexpr (!kStampsBuild) {   // (a stamps build keeps full waves: its eight slots are the wave's first eight envs)
+        while (epw >= 2 && (a.E + epw / 2 - 1) / (epw / 2) <= RG_MAX_WAVES) epw /= 2;
+        a.envs_per_wave = epw;
+    }
     const int grid = (a.E + epw - 1) / epw;
     if constexpr (!OBS_ONLY && !ROLLOUT) {
         if (a.io.elapsed) {  // gymma block: its own instantiations (generic agent count)

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "device_common.h"
+#include "probes/diag.h"   // diagnostic hooks: every RG_* macro below expands to nothing in the shipped build
 
 namespace rg {
 namespace tpe {
@@ -237,15 +238,7 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
 // the fences only pin the compiler's order.
 // 16 KB: eight one-wave workgroups per CU (two waves per SIMD) fit the CU's 160 KB; 12 KB for the instantiations that
 // run three waves per SIMD (N <= 4: twelve workgroups per CU)
-#ifndef RG_TPE_W4
-#define RG_TPE_W4 3   // waves per SIMD the N <= 4 instantiations are compiled for
-#endif
-#ifndef RG_TPE_W5
-#define RG_TPE_W5 0   // N = 5 (0 = the compiler's own allocation: two)
-#endif
-#ifndef RG_TPE_W78
-#define RG_TPE_W78 1  // N = 7, 8
-#endif
+// (RG_TPE_W4 / W5 / W78: waves per SIMD the instantiations are compiled for; defaults in probes/diag.h)
 constexpr int tpe_waves(int n) { return n <= 4 ? RG_TPE_W4 : n == 5 ? RG_TPE_W5 : n == 6 ? 2 : RG_TPE_W78; }
 // the wave's LDS block in floats: as many one-wave workgroups as the SIMDs' wave slots must fit a CU's 160 KB
 template <int N>
@@ -259,17 +252,9 @@ struct Stage {
     int nact;     // envs of this wave (64 except in the batch's last wave)
     size_t env0;  // first env of the wave
     size_t e;     // this lane's env (lanes past the end of the batch: its last env)
-#ifdef RG_TPE_GUARD  // diagnostic build (tests/guard_probe.py): a store outside its array is dropped and flagged in
-    int *flag;    // done_count[0] instead of faulting
-    int E;
-#endif
+    int *flag;    // -DRG_TPE_GUARD builds only (tests/guard_probe.py): a store outside its array is dropped and flagged in
+    int E;        // done_count[0] instead of faulting (RG_GUARDED, probes/diag.h); dead in the shipped build
 };
-#ifdef RG_TPE_GUARD
-#define RG_GUARDED(dst, lo, hi, code, stmt) \
-    if ((dst) < (lo) || (dst) >= (hi)) atomicOr(sg.flag, (code)); else { stmt; }
-#else
-#define RG_GUARDED(dst, lo, hi, code, stmt) stmt
-#endif
 
 __device__ __forceinline__ void stage_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
@@ -388,11 +373,7 @@ __device__ __forceinline__ void stage_obs_rows(const Stage &sg, float *obs, int 
     static_assert(RP >= 1, "one observation row of the whole wave must fit the staging block");
     // D > DMAX: a parameter block that asks for more neighbour slots than there are other agents (rows wider than the
     // agents fill, misc.py:20-25 / PredatorCapturePrey.py:198-201) -- the batch would overrun the staging block
-#ifdef RG_TPE_NO_DMAX_GUARD  // (test of the tests only: the round-2 condition, to show that the configuration fuzzer sees the overrun)
-    if ((D & 3) != 0) {
-#else
     if ((D & 3) != 0 || D > DMAX) {
-#endif
         float *mine = obs + sg.e * N * D;
         sfor<0, N>([&](auto AA) { fn(AA, mine + decltype(AA)::value * D); });
         return;
@@ -404,11 +385,7 @@ __device__ __forceinline__ void stage_obs_rows(const Stage &sg, float *obs, int 
         fn(AA, sg.buf + (sg.lane * CNT + (A - A0)) * D);
         if constexpr (A == A0 + CNT - 1) {
             stage_fence();
-#ifdef RG_TPE_GUARD
-            const float *lo = obs, *hi = obs + static_cast<size_t>(sg.E) * N * D;
-#else
-            const float *lo = nullptr, *hi = nullptr;
-#endif
+            const float *lo = kTpeGuard ? obs : nullptr, *hi = kTpeGuard ? obs + static_cast<size_t>(sg.E) * N * D : nullptr;
             copy_runs<4>(sg, sg.buf, g0 + A0 * D, CNT * D, N * D, lo, hi);
             stage_fence();
         }
@@ -437,13 +414,7 @@ __device__ __forceinline__ void write_obs_staged(const float (&x)[N], const floa
 // returns whether the episode ended (roboEnv.py:38-96 + the scenario's step())
 template <int SCN, int N>
 __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv, const int e, int &rc_raw, const Stage &sg) {
-#ifdef RG_STAMPS  // diagnostic build only (tools/stamp_probe.py): wave-cycle stamps of the step's phases, written over
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();  // io.qp_sweeps of the wave's first 8 envs
-    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define RG_TSTAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
-#else
-#define RG_TSTAMP(i)
-#endif
+    RG_STAMPS_BEGIN()
     const rg_scenario_params &p = a.p;
     const Consts &k = a.k;
     const size_t eN = static_cast<size_t>(e) * N;
@@ -452,9 +423,8 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     // field at its first use; see step_group.h), then ALL the loads before anything waits for one of them
     const float *q_poses = a.st.poses, *q_carry = a.st.carry_dist, *q_ret = a.st.ep_return, *q_sum = a.st.done_return_sum;
     const int32_t *q_steps = a.st.episode_steps, *q_act = sv.actions, *q_cnt = a.st.done_count, *q_stp = a.st.done_steps_sum;
-#ifndef RG_HOST_SIM  // (scheduling hint only; the host simulation of tests/sanitize/ has no "s" registers)
-    asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp));
-#endif
+    if constexpr (!kHostSim)   // (scheduling hint only; the host simulation of tests/sanitize/ has no "s" registers)
+        asm volatile("" ::"s"(q_poses), "s"(q_carry), "s"(q_ret), "s"(q_sum), "s"(q_steps), "s"(q_act), "s"(q_cnt), "s"(q_stp));
     float x[N], y[N], th[N], acc[N], last[N];
     int act[N];
     int pix[N];
@@ -475,13 +445,8 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = q_carry[eN + i];  // dist incl. the pending sub-step (first used at the period end)
     }
-#ifdef RG_STAMPS
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]), "v"(y[i]), "v"(th[i]), "v"(act[i]), "v"(acc[i]));
-#ifndef RG_STAMPS_EPI
-    RG_TSTAMP(0);  // inputs loaded
-#endif
-#endif
+    RG_PIN_ARR5(N, x, y, th, act, acc);
+    RG_TSTAMP_MAIN(0);  // inputs loaded
     // (step counter, reset counter and statistics words are fetched in the epilogue, where they are used: this kernel
     // has no register to spare -- a value more live through the step costs its second wave per SIMD -- and the second
     // wave hides the latency)
@@ -511,9 +476,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 
     // ---- a2 roboEnv.step, one controller period at a time (float spec of oracle/oracle_core.h)
     int viol = 0, max_sweeps = 0;
-#ifdef RG_TPE_DIAG
-    int diag = 0, diag_chunk = 0;
-#endif
+    RG_TPE_DIAG_LOCALS()
     const bool penalize = p.penalize_violations != 0;
     const int U = p.update_frequency, period = p.controller_period;
     const int thr_pre = __builtin_bit_cast(int, k.thr_pre);  // non-negative floats order like their bit patterns
@@ -533,16 +496,9 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         for (int i = 0; i < N; ++i) sincos_spec(th[i], s[i], c[i]);
         const int sw = controller<N>(p, k, x, y, c, s, gx, gy, v, w);
         max_sweeps = sw > max_sweeps ? sw : max_sweeps;
-#ifdef RG_STAMPS
-#pragma unroll
-        for (int i = 0; i < N; ++i) asm volatile("" ::"v"(v[i]), "v"(w[i]));
-#ifndef RG_STAMPS_EPI
-        if (it0 == 0) RG_TSTAMP(1);  // first controller
-#endif
-#endif
-#ifdef RG_TPE_DIAG
-        diag |= sw << (it0 == 0 ? 8 : 0);
-#endif
+        RG_PIN_ARR2(N, v, w);
+        if (it0 == 0) RG_TSTAMP_MAIN(1);  // first controller
+        RG_TPE_DIAG_SWEEPS(sw, it0);
         float dtv[N], dtw[N], sd[N], cd[N], mrg[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -621,9 +577,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 advance(x, y, ox, oy, c, s);
             });
             if (penalize && ((dmin <= thr_pre) | bnd_any)) {
-#ifdef RG_TPE_DIAG
-                diag |= 1 << (16 + (it0 ? 3 : 0) + j0 / CH);
-#endif
+                RG_TPE_DIAG_REPLAY(it0, j0, CH);
                 // rare: replay the chunk with the exact float tests of _validate (roboEnv.py:82-94)
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
@@ -667,17 +621,10 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             bx[i] = x[i];
             by[i] = y[i];
         }
-#ifdef RG_STAMPS
-#pragma unroll
-        for (int i = 0; i < N; ++i) asm volatile("" ::"v"(x[i]), "v"(y[i]), "v"(th[i]));
-#ifndef RG_STAMPS_EPI
-        if (it0 == 0) RG_TSTAMP(2);  // first period
-#else
-        if (it0 != 0) RG_TSTAMP(2);  // last period (the epilogue's loads are issued after it)
-#endif
-#endif
+        RG_PIN_ARR3(N, x, y, th);
+        RG_TSTAMP_PERIOD(it0);
     }
-    RG_TSTAMP(3);  // all periods
+    RG_STAMP(3);  // all periods
     float dist[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) dist[i] = viol ? acc[i] : acc[i] - last[i];
@@ -766,11 +713,8 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         } else {
             for (int q = 0; q < P; ++q) prey_step(pl[2 * q], pl[2 * q + 1], sen[q] != 0, cap[q] != 0, q);
         }
-#ifdef RG_STAMPS_EPI  // (with RG_STAMPS) slots 0..2 mark points inside the PredatorCapturePrey epilogue instead
-#pragma unroll
-        for (int i = 0; i < N; ++i) asm volatile("" ::"v"(qx[i]), "v"(qy[i]));
-        RG_TSTAMP(0);  // prey tracked
-#endif
+        RG_PIN_ARR2(N, qx, qy);
+        RG_TSTAMP_EPI(0);  // prey tracked
         if (p.capability_aware) {
             float own[N][6];
 #pragma unroll
@@ -793,9 +737,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
                 own[i][3] = qy[i];
             }
             write_obs_staged<N, 4, 4 * N>(x, y, own, p.num_neighbors, sg, sv.io.obs, D, [](float *) {});
-#ifdef RG_STAMPS_EPI
-            RG_TSTAMP(1);  // observation rows written and copied out
-#endif
+            RG_TSTAMP_EPI(1);  // observation rows written and copied out
         }
         float r;
         if (viol) {
@@ -1025,7 +967,7 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
     }
 
     // ---- stores
-    RG_TSTAMP(4);  // scenario epilogue (observation rows already on their way)
+    RG_STAMP(4);  // scenario epilogue (observation rows already on their way)
     bool trunc = false;
     {
         float rsum = 0.0f;
@@ -1044,18 +986,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             }
             stage_fence();
             const size_t w0 = sg.env0 * N;
-#ifdef RG_TPE_GUARD
-            const size_t EN = static_cast<size_t>(a.E) * N;
+            const size_t EN = static_cast<size_t>(a.E) * N;   // (array bounds: read by -DRG_TPE_GUARD builds only)
             copy_span<3 * N>(sg, sg.buf, a.st.poses + w0 * 3, sg.nact * (3 * N), a.st.poses, a.st.poses + EN * 3);
             copy_span<N>(sg, sg.buf + WAVE * (3 * N), a.st.carry_dist + w0, sg.nact * N, a.st.carry_dist, a.st.carry_dist + EN);
             copy_span<N>(sg, sg.buf + WAVE * (4 * N), sv.io.reward + w0, sg.nact * N, sv.io.reward, sv.io.reward + EN);
             copy_span<N>(sg, sg.buf + WAVE * (5 * N), sv.io.dist_travelled + w0, sg.nact * N, sv.io.dist_travelled, sv.io.dist_travelled + EN);
-#else
-            copy_span<3 * N>(sg, sg.buf, a.st.poses + w0 * 3, sg.nact * (3 * N));
-            copy_span<N>(sg, sg.buf + WAVE * (3 * N), a.st.carry_dist + w0, sg.nact * N);
-            copy_span<N>(sg, sg.buf + WAVE * (4 * N), sv.io.reward + w0, sg.nact * N);
-            copy_span<N>(sg, sg.buf + WAVE * (5 * N), sv.io.dist_travelled + w0, sg.nact * N);
-#endif
             stage_fence();
         }
         a.st.episode_steps[e] = steps;
@@ -1083,19 +1018,11 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         sv.io.done[e] = done ? 1 : 0;
         sv.io.violation[e] = static_cast<uint8_t>(viol);
         sv.io.remaining[e] = remaining;
-#ifdef RG_TPE_DIAG
-        max_sweeps = diag;  // diagnostic build: replayed-chunk mask << 16 | sweeps of QP 1 << 8 | sweeps of QP 2
-#endif
+        RG_TPE_DIAG_REPORT(max_sweeps);
         if (sv.io.qp_sweeps) sv.io.qp_sweeps[e] = max_sweeps;
     }
-#ifdef RG_STAMPS
-    RG_TSTAMP(5);
-    if (sg.lane == 0 && sv.io.qp_sweeps) {
-        stamps[7] = max_sweeps;
-        for (int i = 0; i < 8; ++i)
-            if (e + i < a.E) sv.io.qp_sweeps[e + i] = stamps[i];
-    }
-#endif
+    RG_STAMP_ALWAYS_5();
+    RG_STAMPS_WRITE(sg.lane, sv.io.qp_sweeps, e, a.E, max_sweeps)
     return done | trunc;
 }
 
@@ -1107,9 +1034,7 @@ template <int SCN, int N, bool ROLLOUT>
 // scratch; one wave per SIMD measured 34 % slower in round 2), N >= 7 one.  Measured and rejected in round 3 at 524 288 envs
 // (tools/tpe_ab_probe.py, -DRG_TPE_W5=3 / -DRG_TPE_W4=4 / -DRG_TPE_W78=2): N = 5 at three waves (32 spilled) 169.6 vs
 // 153.1 us, N = 4 at four (18 spilled) 108.7 vs 99.5, N = 7 at two (93 spilled) 390.6 vs 348.0, N = 8 at two 1448 vs 481.
-#ifndef RG_TPE_NO_W3
-__attribute__((amdgpu_waves_per_eu(tpe_waves(N) ? tpe_waves(N) : 1)))
-#endif
+RG_TPE_WAVES_ATTR(tpe_waves(N) ? tpe_waves(N) : 1)
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ union alignas(16) {
         Lds<WAVE> reset;        // fused reset (after the step, behind a barrier)
@@ -1120,19 +1045,12 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     // All 64 lanes run the step (the staged stores are copied out by the whole wave): lanes past the end of the batch
     // repeat its last env -- the same loads, the same values, the same stores -- and take no part in the fused reset.
     const int e_raw = chunk * WAVE + threadIdx.x;
-#ifndef RG_HOST_SIM
-    const int e = e_raw < a.E ? e_raw : a.E - 1;
-#else  // host simulation (tests/sanitize/): lanes are threads, not in lock step, so the surplus lanes of the last wave cannot share
-    const int e = e_raw;  // env E - 1's read-modify-writes; the harness pads every array to whole waves with copies of that env
-#endif
+    // host simulation (tests/sanitize/): lanes are threads, not in lock step, so the surplus lanes of the last wave cannot share
+    // env E - 1's read-modify-writes; the harness pads every array to whole waves with copies of that env
+    const int e = (kHostSim || e_raw < a.E) ? e_raw : a.E - 1;
     const int left = a.E - chunk * WAVE;
-#ifdef RG_TPE_GUARD
     const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE,
                    static_cast<size_t>(e), a.st.done_count, a.E};
-#else
-    const Stage sg{shm.stage, static_cast<int>(threadIdx.x), left < WAVE ? left : WAVE, static_cast<size_t>(chunk) * WAVE,
-                   static_cast<size_t>(e)};
-#endif
     const int num_steps = ROLLOUT ? a.num_steps : 1;  // rg_rollout: no device-wide synchronisation between steps
     for (int t = 0; t < num_steps; ++t) {
         if (t) __syncthreads();  // the previous step's stores and resets are visible to the wave

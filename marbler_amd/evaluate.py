@@ -96,6 +96,9 @@ class BatchedActor(object):
                         raise _lib.RobogymError("rg_actor_pack_gru: " + lib.rg_actor_last_error().decode())
                     t[k] = dst
                 packed = 2 if self.pack_gru == "bf16x3" else 1
+                # a first launch on ANOTHER stream must not overtake the two pack kernels (forward_fused waits on this once)
+                self._pack_done = torch.cuda.Event()
+                self._pack_done.record(torch.cuda.current_stream(self.w1.device))
             if not self.use_rnn:
                 t.update({"wih": self.wr.contiguous(), "bih": self.br.contiguous()})
             ptr = lambda k: t[k].data_ptr() if k in t else None  # noqa: E731
@@ -120,7 +123,14 @@ class BatchedActor(object):
             actions_out = torch.empty(E, N, dtype=torch.int32, device=obs.device)
         if stream is None:
             stream = torch.cuda.current_stream(obs.device)
-        rc = lib.rg_actor_forward(C.byref(self._weights_struct()), E, N, obs.data_ptr(), D, 1 if append_agent_id else 0,
+        ws = self._weights_struct()
+        ev = getattr(self, "_pack_done", None)
+        if ev is not None:   # the weights were packed (once) on the then-current stream: order this stream behind them
+            if ev.query():
+                self._pack_done = None
+            else:
+                stream.wait_event(ev)
+        rc = lib.rg_actor_forward(C.byref(ws), E, N, obs.data_ptr(), D, 1 if append_agent_id else 0,
                                   restart.data_ptr() if restart is not None else None, hidden.data_ptr(),
                                   q_out.data_ptr(), actions_out.data_ptr(), C.c_void_p(stream.cuda_stream))
         if rc != 0:

@@ -86,11 +86,25 @@ def make_params(scenario, cfg):
         raise ValueError("real_time: True paces the simulator to wall-clock time (rps sim_in_real_time): not a batched mode "
                          "(the single-env `Wrapper` honours it: marbler_amd/wrapper.py)")
     bc = cfg.get("barrier_certificate", "safe")                # roboEnv.py:15-18
+    if bc == "custom" or callable(bc):
+        raise ValueError("barrier_certificate: custom -- Controller(type='custom', custom=<closure>) (utilities/controller.py:17-18) hands "
+                         "the QP to a Python callable, which a batched device engine cannot run.  The PARAMETRIC family rps offers is "
+                         "reachable from the config instead: barrier_certificate: safe|default (certificate2 | certificate) with the "
+                         "keys safety_radius, barrier_gain, unsafe_barrier_gain, magnitude_limit overriding their defaults")
     if bc not in ("safe", "default"):
-        raise ValueError("barrier_certificate must be 'safe' or 'default' (custom closures are not supported)")
+        raise ValueError("barrier_certificate must be 'safe' or 'default'")
     p.barrier_has_unsafe_gain = 1 if bc == "safe" else 0       # controller.py:13-16
-    p.safety_radius = 0.2 if bc == "safe" else 0.17
-    p.barrier_gain, p.unsafe_barrier_gain, p.barrier_magnitude_limit = 100.0, 1e6, 0.2
+    # the arguments of rps' create_single_integrator_barrier_certificate{2,}: the reference passes safety_radius=.2 for 'safe'
+    # and leaves the rest at rps' defaults; a config may set any of them -- what the reference would
+    # write as Controller('custom', create_single_integrator_barrier_certificate2(barrier_gain=..., safety_radius=...))
+    p.safety_radius = float(cfg.get("safety_radius", 0.2 if bc == "safe" else 0.17))
+    p.barrier_gain = float(cfg.get("barrier_gain", 100.0))
+    p.unsafe_barrier_gain = float(cfg.get("unsafe_barrier_gain", 1e6))
+    p.barrier_magnitude_limit = float(cfg.get("magnitude_limit", 0.2))
+    for key, val in (("safety_radius", p.safety_radius), ("barrier_gain", p.barrier_gain), ("unsafe_barrier_gain", p.unsafe_barrier_gain),
+                     ("magnitude_limit", p.barrier_magnitude_limit)):
+        if not (val > 0.0 and math.isfinite(val)):
+            raise ValueError(f"{key} must be a positive finite number (got {val!r})")
     p.qp_rtol = float(cfg.get("qp_rtol", QP_RTOL))
     p.qp_max_sweeps = int(cfg.get("qp_max_sweeps", QP_MAX_SWEEPS))
     p.collision_variant = COLLISION_VARIANTS[cfg.get("collision_variant", DEFAULT_COLLISION_VARIANT)]

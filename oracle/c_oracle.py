@@ -34,6 +34,7 @@ class OrcParams(C.Structure):
         ("barrier_gain", C.c_double), ("unsafe_barrier_gain", C.c_double), ("safety_radius", C.c_double),
         ("barrier_magnitude_limit", C.c_double), ("qp_rtol", C.c_double), ("qp_max_sweeps", C.c_int32),
         ("qp_mode", C.c_int32),
+        ("ipm_abstol", C.c_double), ("ipm_reltol", C.c_double), ("ipm_feastol", C.c_double), ("ipm_maxiters", C.c_int32), ("pad_", C.c_int32),
         ("left", C.c_double), ("right", C.c_double), ("up", C.c_double), ("down", C.c_double),
         ("agent_step", C.c_double * MAXN), ("sensing_radius", C.c_double * MAXN),
         ("capture_radius", C.c_double * MAXN),
@@ -75,9 +76,13 @@ def params_from_config(scenario, cfg, collision_variant="offset", dtype=np.float
     p = OrcParams()
     p.qp_rtol = cfg.get("qp_rtol", QP_RTOL[np.dtype(dtype).name])
     p.qp_max_sweeps = cfg.get("qp_max_sweeps", QP_MAX_SWEEPS[np.dtype(dtype).name])
-    if cfg.get("qp_solver", "exact") == "cvxopt_restated":   # study mode (float64 tier): oracle_core.h barrier_qp_ipm
-        assert np.dtype(dtype) == np.float64, "the interior-point study mode exists in the float64 tier only"
-        p.qp_mode, p.qp_rtol, p.qp_max_sweeps = 1, cfg.get("cvxopt_reltol", 1e-2), cfg.get("cvxopt_maxiters", 50)
+    # barrier_solver: exact (the projection by Hildreth sweeps) | cvxopt (the restated interior-point iterate at rps' options);
+    # `qp_solver: cvxopt_restated` is the round-3/4 spelling of the latter.  ipm_spec_f64: the float spec's operation order in float64.
+    solver = cfg.get("barrier_solver", "cvxopt" if cfg.get("qp_solver", "exact") == "cvxopt_restated" else "exact")
+    assert solver in ("exact", "cvxopt", "ipm_spec"), solver
+    p.qp_mode = {"exact": 0, "cvxopt": 1, "ipm_spec": 2}[solver]
+    p.ipm_abstol, p.ipm_reltol = cfg.get("cvxopt_abstol", 1e-7), cfg.get("cvxopt_reltol", 1e-2)
+    p.ipm_feastol, p.ipm_maxiters = cfg.get("cvxopt_feastol", 1e-2), int(cfg.get("cvxopt_maxiters", 50))
     p.scenario = SCN[scenario]
     p.update_frequency = int(cfg["update_frequency"])
     p.controller_period = 1 if cfg.get("robotarium", False) else 15   # roboEnv.py:63
@@ -86,8 +91,10 @@ def params_from_config(scenario, cfg, collision_variant="offset", dtype=np.float
     bc = cfg.get("barrier_certificate", "safe")   # roboEnv.py:15-18: absent -> Controller() -> 'safe'
     assert bc in ("safe", "default")
     p.barrier_has_unsafe_gain = 1 if bc == "safe" else 0
-    p.safety_radius = 0.2 if bc == "safe" else 0.17   # controller.py:13-16
-    p.barrier_gain, p.unsafe_barrier_gain, p.barrier_magnitude_limit = 100.0, 1e6, 0.2
+    p.safety_radius = cfg.get("safety_radius", 0.2 if bc == "safe" else 0.17)   # controller.py:13-16; the keys below: the
+    p.barrier_gain = cfg.get("barrier_gain", 100.0)                            # arguments of rps' certificate factories (A.6)
+    p.unsafe_barrier_gain = cfg.get("unsafe_barrier_gain", 1e6)
+    p.barrier_magnitude_limit = cfg.get("magnitude_limit", 0.2)
     p.collision_variant = {"center": 0, "offset": 1}[cfg.get("collision_variant", collision_variant)]
     p.time_step = 0.033
     p.bound_x0, p.bound_y0, p.bound_w, p.bound_h = -1.6, -1.0, 3.2, 2.0

@@ -33,8 +33,12 @@ typedef struct orc_params {
     double barrier_gain, unsafe_barrier_gain, safety_radius, barrier_magnitude_limit;
     double qp_rtol;               /* Hildreth stop: max change <= qp_rtol * max(|u|_inf, magnitude_limit) */
     int32_t qp_max_sweeps;
-    int32_t qp_mode;              /* 0: the exact projection (sim_spec_v0).  1, float64 tier only: study mode, a restated cvxopt
-                                     interior-point iterate at qp_rtol = reltol = feastol, qp_max_sweeps = maxiters (oracle_core.h) */
+    int32_t qp_mode;              /* 0: the exact projection (sim_spec_v0).  1: the restated cvxopt interior-point iterate the reference's
+                                     stack computes (float64 tier: in cvxopt's operation order; float tier: ipm_spec_v0 = the kernels).
+                                     2: ipm_spec_v0 in either precision (float64: the study twin of the spec).  oracle_core.h */
+    double ipm_abstol, ipm_reltol, ipm_feastol; /* cvxopt options as rps sets them: abstol 1e-7 (default), reltol = feastol = 1e-2 */
+    int32_t ipm_maxiters;                       /* 50 */
+    int32_t pad_;
     /* scenario */
     double left, right, up, down;
     double agent_step[ORC_MAXN];      /* step_dist, or MaterialTransport per-agent speed */

@@ -340,9 +340,9 @@ static int FN(chol_solve)(int n, REAL *M, REAL *b) { /* M (n x n, row-major, SPD
 static int FN(barrier_qp_ipm)(const orc_params *p, int N, const REAL *xix, const REAL *xiy, REAL *ux, REAL *uy) {
     const int n = 2 * N;
     int m = 0;
-    static const REAL ABSTOL = 1e-7, STEP = 0.99;
-    const REAL RELTOL = p->qp_rtol > 0 ? p->qp_rtol : 1e-2, FEASTOL = RELTOL;
-    const int MAXITERS = p->qp_max_sweeps > 0 ? p->qp_max_sweeps : 50;
+    static const REAL STEP = 0.99;
+    const REAL ABSTOL = p->ipm_abstol, RELTOL = p->ipm_reltol, FEASTOL = p->ipm_feastol;
+    const int MAXITERS = p->ipm_maxiters;
     REAL r2 = R(p->safety_radius) * R(p->safety_radius);
     /* rows in rps' order (i < j, i outer); vec(u) column-major: u[2a] = x of robot a, u[2a+1] = y */
     static _Thread_local REAL G[ORC_MAXC][ORC_MAXV];
@@ -484,6 +484,279 @@ static int FN(barrier_qp_ipm)(const orc_params *p, int N, const REAL *xix, const
 }
 #endif
 
+#if !ORC_IS_F32
+/* a6, qp_mode == 1 of the float spec ("ipm_spec_v0"): the barrier QP solved the way the reference's stack solves it --
+ * rps hands `qp(H = 2I, f = -2 vec(uhat), A, b)` to cvxopt at reltol = feastol = 1e-2, maxiters 50 (utilities/controller.py:13-16,23
+ * -> rps barrier_certificates), and cvxopt's coneqp returns an interior-point ITERATE that stops strictly
+ * inside the feasible set.  This is the same iteration as barrier_qp_ipm above (restated coneqp for the linear cone: default starting
+ * point, Mehrotra predictor-corrector, step 0.99 to the boundary, the same stopping rule), written as the explicit sequence of IEEE
+ * BINARY64 operations the HIP kernels execute (csrc/ipm_qp.h) -- the float tier calls this very function on its binary32 xi and
+ * uhat and rounds the result once, so kernels and oracle agree bit for bit.  Why binary64 inside a float spec: the KKT matrix
+ * 2I + G' diag(z/s) G reaches condition numbers of 1e6 .. 1e8 near the boundary (z/s up to 1e7 under the 1e6 unsafe gain), and
+ * cvxopt's stopping rule holds the dual residual against an ABSOLUTE 1e-2 while the multipliers are ~1e4: a binary32 transcription
+ * misses the stop (residual noise 1.5e-2), runs on to maxiters and ends in NaN (measured, tests/test_ipm_spec.py).  MI355X
+ * issues v_fma_f64 at the binary32 rate, so this costs registers, not issue slots.
+ *   - rows keep rps' order (i < j, i outer); a row is never stored: G x and G' z are formed from e_c = xi_i - xi_j (exact in binary64);
+ *   - K = 2I + G' diag(w) G is assembled in its 2 x 2 block form (diagonal blocks sum w e e' over the partners in row order, an
+ *     off-diagonal block is -w e e' of its one pair) and factored K = L D L' without square roots; every solve is forward, scale,
+ *     backward with fma chains in ascending index order;
+ *   - ONE reciprocal per row per iteration (1 / s_c) and one per pivot; the step to the boundary max(-ds/s, -dz/z) is found by
+ *     cross-multiplied comparisons (a/b > c/d  <=>  a d > c b, all denominators positive) and divided once;
+ *   - no square root anywhere: the residual tests compare squared norms (|r| <= tol max(1, |r0|)  <=>  r.r <= tol^2 max(1, r0.r0));
+ *   - sums run in ascending index order, left to right.
+ * Like everything below the reference's own layers this is PARITY UNPINNED against real cvxopt; against barrier_qp_ipm it differs by
+ * rounding only (tests/test_ipm_spec.py). */
+#define ORC_IPM_MAXN 8
+#define ORC_IPM_MAXV (2 * ORC_IPM_MAXN)
+#define ORC_IPM_MAXC (ORC_IPM_MAXN * (ORC_IPM_MAXN - 1) / 2)
+/* K (lower triangle, row-major n x n storage) <- 2I + sum_c w_c a_c a_c', a_c = -2 e_c at robot i, +2 e_c at robot j: with
+ * W = 4 w the blocks are +-W e e' */
+static void ipm_assemble(int N, const double *ex, const double *ey, const double *w4, double *K) {
+    const int n = 2 * N;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c <= r; ++c) K[r * n + c] = r == c ? 2.0 : 0.0;
+    int c = 0;
+    for (int i = 0; i < N - 1; ++i)
+        for (int j = i + 1; j < N; ++j, ++c) {
+            const double a = w4[c] * ex[c], b = w4[c] * ey[c];
+            const double wxx = a * ex[c], wxy = a * ey[c], wyy = b * ey[c];
+            K[(2 * i) * n + 2 * i] = K[(2 * i) * n + 2 * i] + wxx;
+            K[(2 * i + 1) * n + 2 * i] = K[(2 * i + 1) * n + 2 * i] + wxy;
+            K[(2 * i + 1) * n + 2 * i + 1] = K[(2 * i + 1) * n + 2 * i + 1] + wyy;
+            K[(2 * j) * n + 2 * j] = K[(2 * j) * n + 2 * j] + wxx;
+            K[(2 * j + 1) * n + 2 * j] = K[(2 * j + 1) * n + 2 * j] + wxy;
+            K[(2 * j + 1) * n + 2 * j + 1] = K[(2 * j + 1) * n + 2 * j + 1] + wyy;
+            K[(2 * j) * n + 2 * i] = -wxx;
+            K[(2 * j) * n + 2 * i + 1] = -wxy;
+            K[(2 * j + 1) * n + 2 * i] = -wxy;
+            K[(2 * j + 1) * n + 2 * i + 1] = -wyy;
+        }
+}
+/* in place: K <- unit lower L (below the diagonal), rd <- 1 / D */
+static void ipm_ldl(int n, double *K, double *rd) {
+    double v[ORC_IPM_MAXV];
+    for (int j = 0; j < n; ++j) {
+        double d = K[j * n + j];
+        for (int k = 0; k < j; ++k) {
+            v[k] = K[j * n + k] * K[k * n + k]; /* L_jk D_k */
+            d = __builtin_fma(-K[j * n + k], v[k], d);
+        }
+        K[j * n + j] = d;
+        rd[j] = 1.0 / d;
+        for (int i = j + 1; i < n; ++i) {
+            double t = K[i * n + j];
+            for (int k = 0; k < j; ++k) t = __builtin_fma(-K[i * n + k], v[k], t);
+            K[i * n + j] = t * rd[j];
+        }
+    }
+}
+static void ipm_solve(int n, const double *K, const double *rd, double *b) {
+    for (int i = 1; i < n; ++i) {
+        double t = b[i];
+        for (int k = 0; k < i; ++k) t = __builtin_fma(-K[i * n + k], b[k], t);
+        b[i] = t;
+    }
+    for (int i = 0; i < n; ++i) b[i] = b[i] * rd[i];
+    for (int i = n - 2; i >= 0; --i) {
+        double t = b[i];
+        for (int k = i + 1; k < n; ++k) t = __builtin_fma(-K[k * n + i], b[k], t);
+        b[i] = t;
+    }
+}
+/* xi: the robots' single-integrator points; u: in, the control inputs ALREADY thresholded to the magnitude limit; out, the iterate.
+ * Returns the iteration count (cvxopt's `iterations`). */
+static int barrier_qp_ipm_spec(const orc_params *p, int N, const double *xix, const double *xiy, double *ux, double *uy) {
+    if (N < 2 || N > ORC_IPM_MAXN) return N < 2 ? 0 : -1; /* no rows: the unconstrained minimiser is the input itself */
+    const int n = 2 * N, m = N * (N - 1) / 2;
+    const double ABSTOL = p->ipm_abstol, RELTOL = p->ipm_reltol, FEAS2 = p->ipm_feastol * p->ipm_feastol, STEP = 0.99;
+    const int MAXITERS = p->ipm_maxiters;
+    const double r2 = p->safety_radius * p->safety_radius;
+    double ex[ORC_IPM_MAXC], ey[ORC_IPM_MAXC], h[ORC_IPM_MAXC], s[ORC_IPM_MAXC], z[ORC_IPM_MAXC], w4[ORC_IPM_MAXC];
+    double rz[ORC_IPM_MAXC], rs[ORC_IPM_MAXC], ds[ORC_IPM_MAXC], dz[ORC_IPM_MAXC], dsdza[ORC_IPM_MAXC];
+    double q[ORC_IPM_MAXV], x[ORC_IPM_MAXV], rx[ORC_IPM_MAXV], dx[ORC_IPM_MAXV], rd[ORC_IPM_MAXV], K[ORC_IPM_MAXV * ORC_IPM_MAXV];
+    double nh = 0.0;
+    {
+        int c = 0;
+        for (int i = 0; i < N - 1; ++i)
+            for (int j = i + 1; j < N; ++j, ++c) {
+                ex[c] = xix[i] - xix[j];
+                ey[c] = xiy[i] - xiy[j];
+                const double hh = __builtin_fma(ex[c], ex[c], ey[c] * ey[c]) - r2;
+                const double gain = (hh >= 0.0 || !p->barrier_has_unsafe_gain) ? p->barrier_gain : p->unsafe_barrier_gain;
+                h[c] = gain * ((hh * hh) * hh);
+                nh = __builtin_fma(h[c], h[c], nh);
+                w4[c] = 4.0;
+            }
+    }
+    double nq = 0.0;
+    for (int a = 0; a < N; ++a) {
+        q[2 * a] = -2.0 * ux[a];
+        q[2 * a + 1] = -2.0 * uy[a];
+        nq = __builtin_fma(q[2 * a], q[2 * a], nq);
+        nq = __builtin_fma(q[2 * a + 1], q[2 * a + 1], nq);
+    }
+    const double resx0sq = FEAS2 * (nq > 1.0 ? nq : 1.0), resz0sq = FEAS2 * (nh > 1.0 ? nh : 1.0);
+    /* default starting point: (2I + G'G) x = -q + G'h;  z = G x - h;  s = -z;  both shifted into the cone if they are not inside */
+    ipm_assemble(N, ex, ey, w4, K);
+    ipm_ldl(n, K, rd);
+    for (int k = 0; k < n; ++k) x[k] = -q[k];
+    {
+        int c = 0;
+        for (int i = 0; i < N - 1; ++i)
+            for (int j = i + 1; j < N; ++j, ++c) {
+                const double t = 2.0 * h[c];
+                x[2 * i] = __builtin_fma(-t, ex[c], x[2 * i]);
+                x[2 * i + 1] = __builtin_fma(-t, ey[c], x[2 * i + 1]);
+                x[2 * j] = __builtin_fma(t, ex[c], x[2 * j]);
+                x[2 * j + 1] = __builtin_fma(t, ey[c], x[2 * j + 1]);
+            }
+    }
+    ipm_solve(n, K, rd, x);
+    double gap;
+    {
+        double ns = 0.0, tz = -1e300, ts = -1e300;
+        int c = 0;
+        for (int i = 0; i < N - 1; ++i)
+            for (int j = i + 1; j < N; ++j, ++c) {
+                const double gx_ = 2.0 * __builtin_fma(ex[c], x[2 * j] - x[2 * i], ey[c] * (x[2 * j + 1] - x[2 * i + 1]));
+                z[c] = gx_ - h[c];
+                s[c] = -z[c];
+                ns = __builtin_fma(z[c], z[c], ns);
+                ts = z[c] > ts ? z[c] : ts;   /* max(-s) */
+                tz = s[c] > tz ? s[c] : tz;   /* max(-z) */
+            }
+        /* t >= -1e-8 max(|s|, 1), without the root: t >= 0, or t^2 <= 1e-16 max(s.s, 1) */
+        const double lim2 = 1e-16 * (ns > 1.0 ? ns : 1.0);
+        const int shift_s = ts >= 0.0 || ts * ts <= lim2, shift_z = tz >= 0.0 || tz * tz <= lim2;
+        const double as = 1.0 + ts, az = 1.0 + tz;
+        gap = 0.0;
+        for (c = 0; c < m; ++c) {
+            if (shift_s) s[c] = s[c] + as;
+            if (shift_z) z[c] = z[c] + az;
+            gap = __builtin_fma(s[c], z[c], gap);
+        }
+    }
+    int iters = 0;
+    for (;; ++iters) {
+        /* residuals: rx = q + 2x + G'z, rz = s - h + G x; costs */
+        double f0 = 0.0, nrx = 0.0, nrz = 0.0, zrz = 0.0;
+        for (int k = 0; k < n; ++k) {
+            rx[k] = __builtin_fma(2.0, x[k], q[k]);
+            f0 = __builtin_fma(x[k], rx[k] + q[k], f0); /* x'(Px + q) + x'q, halved below */
+        }
+        f0 = 0.5 * f0;
+        {
+            int c = 0;
+            for (int i = 0; i < N - 1; ++i)
+                for (int j = i + 1; j < N; ++j, ++c) {
+                    const double t = 2.0 * z[c];
+                    rx[2 * i] = __builtin_fma(-t, ex[c], rx[2 * i]);
+                    rx[2 * i + 1] = __builtin_fma(-t, ey[c], rx[2 * i + 1]);
+                    rx[2 * j] = __builtin_fma(t, ex[c], rx[2 * j]);
+                    rx[2 * j + 1] = __builtin_fma(t, ey[c], rx[2 * j + 1]);
+                    const double gx_ = 2.0 * __builtin_fma(ex[c], x[2 * j] - x[2 * i], ey[c] * (x[2 * j + 1] - x[2 * i + 1]));
+                    rz[c] = (s[c] - h[c]) + gx_;
+                    nrz = __builtin_fma(rz[c], rz[c], nrz);
+                    zrz = __builtin_fma(z[c], rz[c], zrz);
+                }
+        }
+        for (int k = 0; k < n; ++k) nrx = __builtin_fma(rx[k], rx[k], nrx);
+        const double pcost = f0, dcost = (f0 + zrz) - gap;
+        /* relgap <= reltol without a division: gap <= reltol * (-pcost) or gap <= reltol * dcost */
+        const int rel_ok = pcost < 0.0 ? gap <= RELTOL * -pcost : dcost > 0.0 ? gap <= RELTOL * dcost : 0;
+#ifdef ORC_IPM_TRACE
+        fprintf(stderr, "spec it %2d gap %.6e pcost %.6e dcost %.6e resx %.3e resz %.3e x0 %.9e\n", iters, gap, pcost, dcost, sqrt(nrx), sqrt(nrz), x[0]);
+#endif
+        if ((nrz <= resz0sq && nrx <= resx0sq && (gap <= ABSTOL || rel_ok)) || iters == MAXITERS) break;
+        /* scaling and the KKT matrix of this iteration */
+        for (int c = 0; c < m; ++c) {
+            rs[c] = 1.0 / s[c];
+            w4[c] = 4.0 * (z[c] * rs[c]);
+        }
+        ipm_assemble(N, ex, ey, w4, K);
+        ipm_ldl(n, K, rd);
+        const double mu = gap / (double)m;
+        double sigmamu = 0.0, step = 1.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            /* rc = -s o z + sigma mu [- dsa o dza];  dx = K^-1 (-rx - G'[(rc + z o rz) / s]) */
+            for (int k = 0; k < n; ++k) dx[k] = -rx[k];
+            {
+                int c = 0;
+                for (int i = 0; i < N - 1; ++i)
+                    for (int j = i + 1; j < N; ++j, ++c) {
+                        const double rc = pass ? __builtin_fma(-s[c], z[c], sigmamu) - dsdza[c] : -(s[c] * z[c]);
+                        const double t = 2.0 * (__builtin_fma(z[c], rz[c], rc) * rs[c]);
+                        dx[2 * i] = __builtin_fma(t, ex[c], dx[2 * i]);        /* - G'(.): the row holds -2e at i, +2e at j */
+                        dx[2 * i + 1] = __builtin_fma(t, ey[c], dx[2 * i + 1]);
+                        dx[2 * j] = __builtin_fma(-t, ex[c], dx[2 * j]);
+                        dx[2 * j + 1] = __builtin_fma(-t, ey[c], dx[2 * j + 1]);
+                    }
+            }
+            ipm_solve(n, K, rd, dx);
+            /* ds = -rz - G dx;  dz = (rc - z o ds) / s;  step to the boundary t = max(0, -ds/s, -dz/z) as a fraction tn / td */
+            double dsdz = 0.0, tn = 0.0, td = 1.0;
+            {
+                int c = 0;
+                for (int i = 0; i < N - 1; ++i)
+                    for (int j = i + 1; j < N; ++j, ++c) {
+                        const double gdx = 2.0 * __builtin_fma(ex[c], dx[2 * j] - dx[2 * i], ey[c] * (dx[2 * j + 1] - dx[2 * i + 1]));
+                        const double rc = pass ? __builtin_fma(-s[c], z[c], sigmamu) - dsdza[c] : -(s[c] * z[c]);
+                        ds[c] = -rz[c] - gdx;
+                        dz[c] = __builtin_fma(-z[c], ds[c], rc) * rs[c];
+                        dsdz = __builtin_fma(ds[c], dz[c], dsdz);
+                        if (-ds[c] * td > tn * s[c]) { tn = -ds[c]; td = s[c]; }
+                        if (-dz[c] * td > tn * z[c]) { tn = -dz[c]; td = z[c]; }
+                    }
+            }
+            if (pass == 0) {
+                step = tn > td ? td / tn : 1.0;                  /* min(1, 1 / t);  t == 0 -> 1 */
+                double sg = __builtin_fma(dsdz / gap, step * step, 1.0 - step);
+                sg = sg < 0.0 ? 0.0 : sg > 1.0 ? 1.0 : sg;
+                sigmamu = ((sg * sg) * sg) * mu;
+                for (int c = 0; c < m; ++c) dsdza[c] = ds[c] * dz[c];
+            } else {
+                step = STEP * td < tn ? (STEP * td) / tn : 1.0;   /* min(1, 0.99 / t) */
+            }
+        }
+        for (int k = 0; k < n; ++k) x[k] = __builtin_fma(step, dx[k], x[k]);
+        gap = 0.0;
+        for (int c = 0; c < m; ++c) {
+            s[c] = __builtin_fma(step, ds[c], s[c]);
+            z[c] = __builtin_fma(step, dz[c], z[c]);
+            gap = __builtin_fma(s[c], z[c], gap);
+        }
+    }
+    for (int a = 0; a < N; ++a) {
+        ux[a] = x[2 * a];
+        uy[a] = x[2 * a + 1];
+    }
+    return iters;
+}
+#endif
+
+/* the float tier's entry (and the float64 tier's qp_mode 2): threshold in the tier's own arithmetic, solve in binary64, round once */
+static int FN(barrier_qp_ipm_spec_call)(const orc_params *p, int N, const REAL *xix, const REAL *xiy, REAL *ux, REAL *uy) {
+    double dxi[ORC_MAXN], dyi[ORC_MAXN], dux[ORC_MAXN], duy[ORC_MAXN];
+    for (int a = 0; a < N; ++a) { /* "Threshold control inputs before QP", decided on squares like the exact mode */
+        REAL n2u = ux[a] * ux[a] + uy[a] * uy[a];
+        if (n2u > R(p->barrier_magnitude_limit) * R(p->barrier_magnitude_limit)) {
+            REAL sc = R(p->barrier_magnitude_limit) / SQRT(n2u);
+            ux[a] = ux[a] * sc;
+            uy[a] = uy[a] * sc;
+        }
+        dxi[a] = (double)xix[a];
+        dyi[a] = (double)xiy[a];
+        dux[a] = (double)ux[a];
+        duy[a] = (double)uy[a];
+    }
+    int it = barrier_qp_ipm_spec(p, N, dxi, dyi, dux, duy);
+    for (int a = 0; a < N; ++a) {
+        ux[a] = (REAL)dux[a];
+        uy[a] = (REAL)duy[a];
+    }
+    return it;
+}
+
 /* a3 = a4 . a5 . a6 . a7, then a8 (utilities/controller.py:20-24, roboEnv.py:64-65) */
 static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL *y, const REAL *cs, const REAL *ss,
                           const REAL *gx, const REAL *gy, REAL *v, REAL *w) {
@@ -502,10 +775,13 @@ static int FN(controller)(const orc_params *p, int N, const REAL *x, const REAL 
         ux[a] = dx;
         uy[a] = dy;
     }
+    /* a6.  qp_mode 0: the exact projection; 1: the restated cvxopt iterate -- in its own operation order in the float64 tier, as
+     * ipm_spec_v0 in the float tier (= the kernels); 2: ipm_spec_v0 in whichever precision (float64: the study twin of the spec) */
 #if !ORC_IS_F32
-    int sweeps = p->qp_mode == 1 ? FN(barrier_qp_ipm)(p, N, xix, xiy, ux, uy) : FN(barrier_qp)(p, N, xix, xiy, ux, uy); /* a6 */
+    int sweeps = p->qp_mode == 1 ? FN(barrier_qp_ipm)(p, N, xix, xiy, ux, uy)
+               : p->qp_mode == 2 ? FN(barrier_qp_ipm_spec_call)(p, N, xix, xiy, ux, uy) : FN(barrier_qp)(p, N, xix, xiy, ux, uy);
 #else
-    int sweeps = FN(barrier_qp)(p, N, xix, xiy, ux, uy); /* a6 */
+    int sweeps = p->qp_mode != 0 ? FN(barrier_qp_ipm_spec_call)(p, N, xix, xiy, ux, uy) : FN(barrier_qp)(p, N, xix, xiy, ux, uy);
 #endif
     REAL inv_pd = R(1) / pd;
     REAL wlim = R(p->angular_velocity_limit);

@@ -4,16 +4,25 @@ Spec: SURVEY.md Appendix A.6.  Reference call sites: utilities/controller.py:2,1
 
 Upstream builds  min ||u - dxi||^2  s.t.  -2 e_ij.u_i + 2 e_ij.u_j <= gamma * h_ij^3
 and hands it to cvxopt's interior-point `qp` at loose tolerances (reltol 1e-2), so its
-answer is an approximate iterate no other solver reproduces.  cvxopt is absent here, so
-sim_spec_v0 defines the EXACT projection, computed by Hildreth's dual coordinate ascent
-in a fixed constraint order (the order the HIP kernel can run pair-parallel: the XOR
-1-factorisation of the lane group).  `solve_pair_qp` below is the float64 statement of
-that spec; tests/test_qp.py checks it against an independent active-set solution
-(scipy NNLS / Lawson-Hanson LDP).
+answer is an approximate iterate no other solver reproduces.  cvxopt is absent here.  Two solvers
+stand in for it, chosen by the module attribute QP_SOLVER (set by the test harness from the config key
+`barrier_solver`):
+  "exact"  (sim_spec_v0's default): the EXACT projection, computed by Hildreth's dual coordinate ascent
+           in a fixed constraint order (the order the HIP kernel can run pair-parallel: the XOR
+           1-factorisation of the lane group).  `solve_pair_qp` below is the float64 statement of
+           that spec; tests/test_qp.py checks it against an independent active-set solution
+           (scipy NNLS / Lawson-Hanson LDP).
+  "cvxopt" : upstream's own formulation (the matrices below are built as rps builds them) handed to the
+           restated interior-point `qp` of oracle/rps_restated/cvxopt_restated.py at rps' options
+           (reltol = feastol = 1e-2, maxiters 50): what `barrier_solver: cvxopt` of the product computes.
 """
 import numpy as np
 from rps.utilities.transformations import *   # upstream star-imports these; controller.py relies on it
 
+import cvxopt_restated  # noqa: E402  (oracle/rps_restated is on sys.path wherever this package is importable)
+
+QP_SOLVER = "exact"
+CVXOPT_OPTIONS = {"reltol": 1e-2, "feastol": 1e-2, "maxiters": 50}   # rps sets these at import (Appendix A.6)
 QP_RTOL_F64 = 5e-12
 QP_MAX_SWEEPS_F64 = 200
 
@@ -117,6 +126,8 @@ def solve_pair_qp(uhat, x, beta, rtol=QP_RTOL_F64, max_sweeps=QP_MAX_SWEEPS_F64,
 def _make_certificate(barrier_gain, unsafe_barrier_gain, safety_radius, magnitude_limit):
     def f(dxi, x):
         N = dxi.shape[1]
+        if QP_SOLVER == "cvxopt":
+            return _certificate_as_upstream(dxi, x, barrier_gain, unsafe_barrier_gain, safety_radius, magnitude_limit)
         beta = {}
         for i in range(N - 1):
             for j in range(i + 1, N):
@@ -134,6 +145,34 @@ def _make_certificate(barrier_gain, unsafe_barrier_gain, safety_radius, magnitud
         u, _ = solve_pair_qp(dxi, x, beta, magnitude_limit=magnitude_limit)
         return u
     return f
+
+
+def _certificate_as_upstream(dxi, x, barrier_gain, unsafe_barrier_gain, safety_radius, magnitude_limit):
+    """The body of rps' certificate closures as recalled (Appendix A.6): dense A (rows -2e at robot i, +2e at robot j), b, H = 2I,
+    f = -2 vec_F(dxi) after the in-place thresholding, then `qp(H, f, A, b)['x']` reshaped column-major."""
+    N = dxi.shape[1]
+    num_constraints = N * (N - 1) // 2
+    A = np.zeros((num_constraints, 2 * N))
+    b = np.zeros(num_constraints)
+    H = 2 * np.identity(2 * N)
+    count = 0
+    for i in range(N - 1):
+        for j in range(i + 1, N):
+            error = x[:, i] - x[:, j]
+            h = (error[0] * error[0] + error[1] * error[1]) - np.power(safety_radius, 2)
+            A[count, (2 * i, (2 * i + 1))] = -2 * error
+            A[count, (2 * j, (2 * j + 1))] = 2 * error
+            if h >= 0 or unsafe_barrier_gain is None:
+                b[count] = barrier_gain * np.power(h, 3)
+            else:
+                b[count] = unsafe_barrier_gain * np.power(h, 3)
+            count += 1
+    norms = np.linalg.norm(dxi, 2, 0)
+    idxs_to_normalize = (norms > magnitude_limit)
+    dxi[:, idxs_to_normalize] *= magnitude_limit / norms[idxs_to_normalize]
+    f = -2 * np.reshape(dxi, 2 * N, order='F')
+    result = cvxopt_restated.qp(H, f, A, b, CVXOPT_OPTIONS)['x']
+    return np.reshape(result, (2, -1), order='F')
 
 
 def create_single_integrator_barrier_certificate(barrier_gain=100, safety_radius=0.17, magnitude_limit=0.2):

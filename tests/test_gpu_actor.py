@@ -138,3 +138,46 @@ def test_fused_actor_random_shapes(seed):
             assert torch.equal(act[clear].long(), q_ref.argmax(dim=2)[clear]), case
         else:
             assert int(act.abs().sum()) == 0, case
+
+
+@pytest.mark.parametrize("A", [1, 5, 20, 32])
+def test_greedy_action_is_a_valid_index_on_non_finite_rows(A):
+    """Rows whose action values are all NaN, all -inf, or mixed: the greedy action is what torch.argmax gives (a NaN counts as the
+    largest value, the first one wins; an all -inf row gives column 0) and ALWAYS an index in [0, A) -- the batched runner feeds it
+    straight back into env.step and into gathers.  The non-finite values are put in through fc2's bias (per agent: non-shared
+    weights), so every other stage of the kernel runs on ordinary numbers."""
+    from marbler_amd.evaluate import BatchedActor
+    dev = "cuda:0"
+    N, H, D = 6, 64, 7
+    sd = _random_actor(N, D, H, A, True, 5)
+    b2 = [k for k in sd if k.endswith("fc2.bias")]
+    assert len(b2) == N, sorted(sd)
+    nan, ninf = float("nan"), float("-inf")
+    for a, k in enumerate(sorted(b2)):
+        b = sd[k].clone()
+        if a == 0:
+            b[:] = nan                       # every column NaN
+        elif a == 1:
+            b[:] = ninf                      # every column -inf
+        elif a == 2 and A > 2:
+            b[A // 2] = nan                  # one NaN among finite values: it wins
+        elif a == 3 and A > 2:
+            b[:] = ninf
+            b[A - 1] = -3.2e38               # below the old sentinel -3.0e38, but the only finite value
+        elif a == 4 and A > 3:
+            b[1] = nan
+            b[A - 2] = nan                   # two NaNs: the first
+        sd[k] = b
+    actor = BatchedActor(sd, N, use_rnn=True, device=dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    E = 70
+    hidden = torch.rand(E, N, H, generator=g, device=dev) * 2 - 1
+    obs = torch.rand(E, N, D, generator=g, device=dev)
+    q_ref, _ = actor.forward(obs, hidden.clone())
+    q, act = actor.forward_fused(obs, hidden, append_agent_id=False)
+    torch.cuda.synchronize()
+    assert int(act.min()) >= 0 and int(act.max()) < A
+    assert torch.equal(torch.isnan(q), torch.isnan(q_ref))
+    want = q_ref.argmax(dim=2)
+    for a in range(5):                       # the rows made non-finite: exactly torch's answer
+        assert torch.equal(act[:, a].long(), want[:, a]), (a, act[:3, a], want[:3, a])

@@ -88,3 +88,30 @@ def test_random_configuration_multi_step_launch_equals_single_steps(i, monkeypat
     scenario, ov, n_act, E, kernel = CASES[i]     # (round 4: shapes whose E*N*D is not a multiple of 4 run too; rg_rollout takes them)
     monkeypatch.setenv("RG_STEP_KERNEL", kernel)
     _rollout_equals_steps(scenario, ov, n_act, E, K=12, reps=3, require_done=False)
+
+
+def draw_barrier_family(rng):
+    """draw_config plus the arguments of rps' certificate factories (config keys safety_radius, barrier_gain,
+    unsafe_barrier_gain, magnitude_limit: what the reference reaches through Controller('custom', create_..._certificate2(...)),
+    utilities/controller.py:11-18).  Radii above the start spacing begin inside the unsafe set (the unsafe gain at work),
+    magnitude limits below the position controller's 0.15 exercise the 'threshold control inputs' branch."""
+    scenario, ov, n_act, E, kernel = draw_config(rng)
+    ov["safety_radius"] = float(rng.choice([0.12, 0.17, 0.2, 0.25, 0.32]))
+    ov["barrier_gain"] = float(rng.choice([10.0, 100.0, 1000.0]))
+    ov["unsafe_barrier_gain"] = float(rng.choice([1e4, 1e6, 1e7]))
+    ov["magnitude_limit"] = float(rng.choice([0.1, 0.15, 0.2, 0.3]))
+    return scenario, ov, n_act, E, kernel
+
+
+BARRIER_CASES = [draw_barrier_family(np.random.RandomState(5000 + i)) for i in range(48)]
+
+
+@pytest.mark.parametrize("i", range(len(BARRIER_CASES)))
+def test_random_barrier_family_is_bit_exact(i, oracle_lib, monkeypatch):
+    scenario, ov, n_act, E, kernel = BARRIER_CASES[i]
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
+    steps = 40 if scenario != "MaterialTransport" else 25
+    try:
+        _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E, require_done=False)
+    except AssertionError as exc:
+        raise AssertionError(f"case {i}: {scenario} {ov} E={E} kernel={kernel}: {exc}") from exc

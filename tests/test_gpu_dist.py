@@ -52,3 +52,24 @@ def test_two_ranks_share_the_gpu_through_the_launcher_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["collective"]["ranks_seen"] == [0, 1] and d["value"] > 1e8
     assert d["config"]["parallelism"] == "env-sharded x2" and d["episodes"]["finished"] > 0
+
+
+def test_four_ranks_share_the_gpu_with_the_drivers_flags():
+    """The driver's multi-GPU command line (`--gpus N --steps 20 --warmup 5`, self-launched ranks, barrier + max over ranks, one
+    timing per rank) with real kernels on every rank: four ranks on cuda:0 (with this process that is five on the card; the box
+    admits six), gloo for the collectives.  What a one-GPU box cannot show is RCCL's transport and the 8-rank job itself (eight
+    ranks with no GPU work: tests/test_host.py)."""
+    env = dict(os.environ, RG_BENCH_NO_LIVE_COUNTERS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dist-backend", "gloo", "--share-gpu",
+                        "--steps", "20", "--warmup", "5"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["steps"] == 20 and d["warmup"] == 5 and d["collective"]["ranks_seen"] == [0, 1, 2, 3]
+    assert len(d["per_rank_ms_per_step"]) == 4 and len(d["per_rank_kernel_ms_per_step"]) == 4 and all(v > 0 for v in d["per_rank_ms_per_step"])
+    assert d["ms_per_step"] == pytest.approx(max(d["per_rank_ms_per_step"]), rel=1e-3)      # the value's clock is the slowest rank's
+    assert d["config"]["parallelism"] == "env-sharded x4" and "spin-up" in d["config"]["workload"]
+    assert d["value"] == pytest.approx(4 * 4096 * 5 / (d["ms_per_step"] * 1e-3), rel=1e-6)

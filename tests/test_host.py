@@ -137,6 +137,16 @@ def test_params_follow_the_reference_configs():
     assert make_params("Warehouse", load_config("Warehouse", overrides={"robotarium": True})).controller_period == 1
     with pytest.raises(ValueError):
         make_params("Warehouse", load_config("Warehouse", overrides={"real_time": True}))
+    # the parametric certificate family (the arguments of rps' factories, utilities/controller.py:11-18) from the config ...
+    b = make_params("Warehouse", load_config("Warehouse", overrides={"barrier_certificate": "default", "safety_radius": 0.25, "barrier_gain": 10,
+                                                                     "unsafe_barrier_gain": 1e4, "magnitude_limit": 0.1}))
+    assert (b.barrier_has_unsafe_gain, b.safety_radius, b.barrier_gain, b.unsafe_barrier_gain, b.barrier_magnitude_limit) == \
+        (0, pytest.approx(0.25), pytest.approx(10.0), pytest.approx(1e4), pytest.approx(0.1))
+    # ... while a Python closure stays refused, with the way out in the message
+    with pytest.raises(ValueError, match="safety_radius, barrier_gain"):
+        make_params("Warehouse", load_config("Warehouse", overrides={"barrier_certificate": "custom"}))
+    with pytest.raises(ValueError, match="positive"):
+        make_params("Warehouse", load_config("Warehouse", overrides={"safety_radius": -0.2}))
     with pytest.raises(KeyError):
         make_params("ArcticTransport", {})
 
@@ -286,6 +296,22 @@ def test_bench_launcher_fails_fast_when_a_rank_dies_before_the_rendezvous():
     assert "rank 1 exited with 7" in r.stderr
     assert took < 60, f"the launcher took {took:.0f} s to notice a dead rank"
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launches_eight_ranks_with_the_drivers_flags_gloo_dry_run():
+    """The driver's N = 8 command line (`--gpus 8 --steps 20 --warmup 5`) through the launcher: eight ranks rendezvous, all eight
+    report in, rank 0's block reaches everyone, the gather returns 8 x 4096 envs and one timing per rank.  (gloo, no GPU work: a
+    one-GPU box admits at most six processes on its card, so the eight-rank job with real kernels cannot be rehearsed there --
+    tests/test_gpu_dist.py runs it with four ranks sharing the GPU.)"""
+    import json
+    r = _run_bench("--gpus", "8", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["collective"]["world_size"] == 8 and d["collective"]["ranks_seen"] == list(range(8))
+    assert len(d["per_rank_ms_per_step"]) == 8 and d["gathered_envs"] == 8 * 4096 and d["gathered_rank_ids"] == list(range(8))
+    assert d["config"]["parallelism"] == "env-sharded x8"
 
 
 def test_bench_launcher_timeout_is_below_the_drivers():
