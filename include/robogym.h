@@ -27,9 +27,11 @@
 extern "C" {
 #endif
 
-/* 5 (round 4): + rg_actor_pack_gru_bf16x3() and rg_actor_weights.gru_packed == 2; rg_rollout takes every shape (no E*N*D % 4
- * rule); the one-lane-per-env step kernel covers N <= 6.  Structs unchanged since 3. */
-#define RG_ABI_VERSION 5
+/* 6 (round 5): rg_scenario_params ends in the barrier-QP solver selection (qp_mode + cvxopt's options): RG_QP_CVXOPT computes the
+ * interior-point iterate the reference's stack computes (utilities/controller.py:13-16,23) instead of the exact projection.
+ * 5 (round 4): + rg_actor_pack_gru_bf16x3() and rg_actor_weights.gru_packed == 2; rg_rollout takes every shape (no E*N*D % 4
+ * rule); the one-lane-per-env step kernel covers N <= 6. */
+#define RG_ABI_VERSION 6
 #define RG_MAX_AGENTS 16
 #define RG_MAX_PREY 64
 
@@ -47,6 +49,13 @@ enum {
 enum { RG_COLLISION_CENTER = 0, RG_COLLISION_OFFSET = 1 };
 /* info['message'] of the reference (utilities/roboEnv.py:82-94) as a code */
 enum { RG_VIOL_NONE = 0, RG_VIOL_COLLISION = 1, RG_VIOL_BOUNDARY = 2, RG_VIOL_COLLISION_BOUNDARY = 3 };
+/* How `si_barrier_cert` (utilities/controller.py:13-16,23: rps' certificate closure -> cvxopt `qp`) is evaluated:
+ * RG_QP_EXACT  -- the exact solution of the QP (the Euclidean projection), by Hildreth sweeps (qp_rtol, qp_max_sweeps);
+ * RG_QP_CVXOPT -- the iterate cvxopt's interior-point method stops at under rps' options (reltol = feastol = 1e-2, maxiters 50,
+ *                 abstol 1e-7): an approximate, strictly interior solution -- what the reference's own stack returns.  Restated
+ *                 coneqp in binary64 (csrc/ipm_qp.h); n_agents <= 8. */
+enum { RG_QP_EXACT = 0, RG_QP_CVXOPT = 1 };
+#define RG_QP_CVXOPT_MAX_AGENTS 8
 
 /* Reset geometry of rps generate_initial_conditions (Appendix A.7) + the scenario's shift
  * (misc.py:49-63, warehouse.py:93-98): N distinct cells of an nx x ny grid;
@@ -100,6 +109,11 @@ typedef struct rg_scenario_params {
     int32_t keep_theta;              /* Warehouse keeps the sampled heading, misc.py:58,62 zero it */
     int32_t shared_reward;           /* config key: episode return adds reward[0] (1) or sum(reward) (0), misc.py:178-181 */
     float zone1_mean, zone1_std, zone2_mean, zone2_std; /* MaterialTransport.py:99-100 */
+    /* barrier QP solver (ABI 6): RG_QP_*; the ipm_* fields are cvxopt's `solvers.options` as rps sets them at import
+     * (abstol 1e-7 = cvxopt's default, reltol = feastol = 1e-2, maxiters 50) and are read in RG_QP_CVXOPT mode only */
+    int32_t qp_mode;
+    float ipm_abstol, ipm_reltol, ipm_feastol;
+    int32_t ipm_maxiters;
 } rg_scenario_params;
 
 /* Env state in HBM (replaces the Python objects: scenario.agent_poses 3xN = the live alias of

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 MAX_AGENTS, MAX_PREY = 16, 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 RESET_BOOK_EPISODE = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,6 +50,7 @@ class RgScenarioParams(C.Structure):
         ("agent_grid", RgGrid), ("prey_grid", RgGrid), ("keep_theta", C.c_int32), ("shared_reward", C.c_int32),
         ("zone1_mean", C.c_float), ("zone1_std", C.c_float), ("zone2_mean", C.c_float),
         ("zone2_std", C.c_float),
+        ("qp_mode", C.c_int32), ("ipm_abstol", C.c_float), ("ipm_reltol", C.c_float), ("ipm_feastol", C.c_float), ("ipm_maxiters", C.c_int32),
     ]
 
 

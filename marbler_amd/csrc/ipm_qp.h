@@ -124,6 +124,8 @@ __device__ __forceinline__ void solve(const double (&K)[N * (2 * N + 1)], const 
 
 // io: N records (xi_x, xi_y, uhat_x, uhat_y) of the env, uhat already thresholded to the magnitude limit; the iterate replaces
 // uhat.  Returns cvxopt's `iterations`.  `io` is a generic pointer (LDS in both kernels).
+// Register budget: callers are one-wave workgroups; the body is compiled for one wave per SIMD (512 registers: 256 + 256
+// accumulation registers as spill space) -- without the attributes a non-kernel function is held to the default 128.
 template <int N>
 __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io) {
     static_assert(N >= 2 && N <= MAX_N, "agent count");

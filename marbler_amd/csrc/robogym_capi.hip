@@ -84,6 +84,12 @@ static int check_params(const rg_scenario_params *p) {
     if (p->update_frequency < 1 || p->controller_period < 1) return fail(-4, "update_frequency / controller_period < 1");
     if (p->obs_dim < 1) return fail(-5, "obs_dim < 1");
     if (p->qp_max_sweeps < 1 || !(p->qp_rtol >= 0.0f)) return fail(-5, "qp_max_sweeps < 1 or qp_rtol < 0");
+    if (p->qp_mode != RG_QP_EXACT && p->qp_mode != RG_QP_CVXOPT) return fail(-5, "unknown qp_mode");
+    if (p->qp_mode == RG_QP_CVXOPT) {
+        if (p->n_agents > RG_QP_CVXOPT_MAX_AGENTS) return fail(-3, "qp_mode RG_QP_CVXOPT is built for n_agents <= 8");
+        if (p->ipm_maxiters < 0 || !(p->ipm_reltol >= 0.0f) || !(p->ipm_feastol > 0.0f) || !(p->ipm_abstol >= 0.0f))
+            return fail(-5, "ipm_maxiters < 0, or a negative / zero cvxopt tolerance");
+    }
     if (p->collision_variant != RG_COLLISION_CENTER && p->collision_variant != RG_COLLISION_OFFSET)
         return fail(-6, "unknown collision_variant");
     const rg_grid &g = p->agent_grid;

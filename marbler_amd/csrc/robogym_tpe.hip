@@ -4,6 +4,7 @@
 namespace rg {
 
 bool tpe_supported(const rg_scenario_params &p) {
+    if (p.qp_mode != RG_QP_EXACT) return false;   // the interior-point mode runs on the lane-group kernel (step_group.h)
     if (p.scenario == RG_SCN_ARCTIC_TRANSPORT) return p.n_agents == 4;
     if (p.scenario == RG_SCN_MATERIAL_TRANSPORT && p.n_agents < 4) return false;
     return p.n_agents >= 2 && p.n_agents <= 6;   // N >= 7: the lane-group kernel at every batch size (step_tpe.h launch_scn)

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "device_common.h"
+#include "ipm_qp.h"
 #include "probes/diag.h"   // diagnostic hooks: every RG_* macro below expands to nothing in the shipped build
 
 namespace rg {
@@ -49,10 +50,12 @@ static_assert(CHUNK >= 1 && CHUNK <= 5, "the sparse collision pre-test covers su
 // ------------------------------------------------------------------ controller (a3..a8)
 // utilities/controller.py:20-24 over the restated rps closures,
 // followed by Robotarium.set_velocities' clipping.  Called in wave-uniform control flow.
-template <int GW>
+// QPM: how the certificate's QP is evaluated (include/robogym.h RG_QP_*): 0 the exact projection by the Hildreth sweeps below,
+// 1 cvxopt's interior-point iterate (ipm_qp.h; qp = the wave's LDS records, one per lane).
+template <int GW, int QPM = 0>
 __device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, int N, int ag, bool lane_ok,
                                           bool upd, float x, float y, float c, float s, float gx, float gy, float &v,
-                                          float &w RG_CTRL_TICKS_PARAM) {
+                                          float &w, float4 *qp RG_CTRL_TICKS_PARAM) {
     RG_CTRL_BEGIN(x, y, c, s)
     // a4 uni_to_si_states, a5 si_position_controller (gain 1, |dxi| <= 0.15)
     const float xix = x + k.pd * c, xiy = y + k.pd * s;
@@ -63,6 +66,41 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         const bool clip = nrm > k.pvl;
         ux = clip ? ux * sc : ux;
         uy = clip ? uy * sc : uy;
+    }
+    if constexpr (QPM == RG_QP_CVXOPT) {
+        // a6 as the reference's stack evaluates it: "threshold control inputs before QP" (decided on squares, as below), then the
+        // env's records gathered in LDS and the interior-point iteration of ipm_qp.h, the same in every lane of the group
+        {
+            const float n2u = ux * ux + uy * uy;
+            const bool clip = n2u > k.bml * k.bml;
+            if (__any(clip)) {
+                const float sc = k.bml / __builtin_sqrtf(n2u);
+                ux = clip ? ux * sc : ux;
+                uy = clip ? uy * sc : uy;
+            }
+        }
+        const int lane_ = threadIdx.x;
+        qp[lane_] = make_float4(xix, xiy, ux, uy);
+        __syncthreads();   // (one wave per workgroup: the records are visible)
+        int iters = 0;
+        if (upd) iters = ipm::solve_qp_n(N, ipm::make_consts(p), qp + (lane_ & ~(GW - 1)));
+        __syncthreads();
+        const float4 r = qp[lane_];
+        ux = r.z;
+        uy = r.w;
+        RG_CTRL_TICK(1);
+        float vv = c * ux + s * uy;
+        float ww = k.inv_pd * (-s * ux + c * uy);
+        ww = ww > k.wlim ? k.wlim : ww;
+        ww = ww < -k.wlim ? -k.wlim : ww;
+        vv = vv > k.vmax ? k.vmax : vv;
+        vv = vv < -k.vmax ? -k.vmax : vv;
+        ww = ww > k.wmax ? k.wmax : ww;
+        ww = ww < -k.wmax ? -k.wmax : ww;
+        v = upd ? vv : v;
+        w = upd ? ww : w;
+        RG_CTRL_TICK(2);
+        return iters;
     }
     // a6 barrier certificate: rows e_ij.(u_j - u_i) <= beta_ij, one per round; the exact projection
     // by Hildreth sweeps with vector-extrapolation restarts (algorithm and derivation: oracle/oracle_core.h
@@ -274,7 +312,7 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
 // the launch costs the MEAN wavefront, and drawing ahead moves the sampler's work without removing any.
 // GYM: the gymma block of rg_step_io (gym's TimeLimit + reductions) is compiled in.  Its own instantiations (generic agent
 // count, single-step launch): the benchmark kernels carry none of it.
-template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD, bool GYM>
+template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD, bool GYM, int QPM = 0>
 __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, const StepView &sv) {
     constexpr int EPW = WAVE / GW;  // envs per wave
     RG_STAMPS_BEGIN()
@@ -530,7 +568,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         for (int it0 = 0; it0 < U; it0 += period) {
             const int n = (U - it0) < period ? (U - it0) : period;
             RG_HEADING_SINCOS(th, s, c);
-            const int sw = controller<GW>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w RG_CTRL_TICKS_ARG);
+            const int sw = controller<GW, QPM>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w, lds.qp RG_CTRL_TICKS_ARG);
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
             const float dtv = k.dt * v, dtw = k.dt * w;
             float sd, cd;
@@ -1249,16 +1287,18 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
 // round-trips through this CU's caches (workgroup-scope visibility after the barrier).  Separate
 // instantiations: the loop keeps more values live (at N = 5 the thread-per-env kernel goes from 237 to
 // 313 VGPRs) and would slow the single-step launch down.
-template <int SCN, int GW, bool OBS_ONLY, int NT, bool ROLLOUT, bool GYM = false>
+// QPM = RG_QP_CVXOPT: the certificate's QP by the interior-point iteration of ipm_qp.h.  Its own instantiations (generic agent
+// count): the launch is then dominated by that iteration (about ten times the rest of the step), and it needs one wave per SIMD.
+template <int SCN, int GW, bool OBS_ONLY, int NT, bool ROLLOUT, bool GYM = false, int QPM = 0>
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ Lds<GW> lds;
     const int N = NT > 0 ? NT : a.p.n_agents;
     if constexpr (!ROLLOUT) {
-        step_once<SCN, GW, OBS_ONLY, NT, true, GYM>(a, lds, step_view(a, 0, N, a.p.obs_dim));
+        step_once<SCN, GW, OBS_ONLY, NT, true, GYM, QPM>(a, lds, step_view(a, 0, N, a.p.obs_dim));
     } else {
         for (int t = 0; t < a.num_steps; ++t) {
             if (t) __syncthreads();
-            step_once<SCN, GW, OBS_ONLY, NT, false, false>(a, lds, step_view(a, t, N, a.p.obs_dim));
+            step_once<SCN, GW, OBS_ONLY, NT, false, false, QPM>(a, lds, step_view(a, t, N, a.p.obs_dim));
         }
     }
 }
@@ -1310,6 +1350,21 @@ static hipError_t launch_step_scn(const KernelArgs &a_in, hipStream_t stream) {
         a.envs_per_wave = epw;
     }
     const int grid = (a.E + epw - 1) / epw;
+    if constexpr (!OBS_ONLY) {
+        if (a.p.qp_mode == RG_QP_CVXOPT) {  // (rg_create admits n_agents <= 8 in this mode)
+            constexpr int Q = RG_QP_CVXOPT;
+            if constexpr (!ROLLOUT) {
+                if (a.io.elapsed) {
+                    if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, false, true, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+                    else hipLaunchKernelGGL((step_kernel<SCN, 8, false, 0, false, true, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+                    return hipGetLastError();
+                }
+            }
+            if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, ROLLOUT, false, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+            else hipLaunchKernelGGL((step_kernel<SCN, 8, false, 0, ROLLOUT, false, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
     if constexpr (!OBS_ONLY && !ROLLOUT) {
         if (a.io.elapsed) {  // gymma block: its own instantiations (generic agent count)
             if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, false, true>), dim3(grid), dim3(WAVE), 0, stream, a);
@@ -1342,6 +1397,21 @@ static hipError_t launch_step_group(const KernelArgs &a, hipStream_t stream) {
         case RG_SCN_SIMPLE:
             return launch_step_scn<RG_SCN_SIMPLE, OBS_ONLY, ROLLOUT>(a, stream);
         case RG_SCN_ARCTIC_TRANSPORT:
+            if constexpr (!OBS_ONLY) {
+                if (a.p.qp_mode == RG_QP_CVXOPT) {
+                    constexpr int Q = RG_QP_CVXOPT;
+                    if constexpr (!ROLLOUT) {
+                        if (a.io.elapsed) {
+                            hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false, 0, false, true, Q>), dim3((a.E + 15) / 16),
+                                               dim3(WAVE), 0, stream, a);
+                            return hipGetLastError();
+                        }
+                    }
+                    hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false, 0, ROLLOUT, false, Q>), dim3((a.E + 15) / 16),
+                                       dim3(WAVE), 0, stream, a);
+                    return hipGetLastError();
+                }
+            }
             if constexpr (!OBS_ONLY && !ROLLOUT) {
                 if (a.io.elapsed) {
                     hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false, 0, false, true>), dim3((a.E + 15) / 16),

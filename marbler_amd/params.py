@@ -16,6 +16,8 @@ from ._lib import MAX_AGENTS, MAX_PREY, RgGrid, RgScenarioParams
 
 SCENARIO_IDS = {"PredatorCapturePrey": 0, "Warehouse": 1, "MaterialTransport": 2, "Simple": 3, "ArcticTransport": 4}
 COLLISION_VARIANTS = {"center": 0, "offset": 1}
+BARRIER_SOLVERS = {"exact": 0, "cvxopt": 1}      # RG_QP_EXACT, RG_QP_CVXOPT
+CVXOPT_MAX_AGENTS = 8
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 
 # sim_spec_v0: which of the two upstream collision tests rps' _validate uses (SURVEY.md
@@ -105,6 +107,16 @@ def make_params(scenario, cfg):
                      ("magnitude_limit", p.barrier_magnitude_limit)):
         if not (val > 0.0 and math.isfinite(val)):
             raise ValueError(f"{key} must be a positive finite number (got {val!r})")
+    # How the certificate's QP is evaluated (include/robogym.h RG_QP_*).  `exact`: the projection (sim_spec_v0's default, Hildreth
+    # sweeps).  `cvxopt`: the interior-point iterate the reference's stack computes -- rps hands the QP to cvxopt at reltol =
+    # feastol = 1e-2, maxiters 50 (utilities/controller.py:13-16,23) -- restated, unpinned against the real
+    # package; cvxopt_* keys = `cvxopt.solvers.options`.
+    solver = cfg.get("barrier_solver", "exact")
+    if solver not in BARRIER_SOLVERS:
+        raise ValueError(f"barrier_solver must be one of {sorted(BARRIER_SOLVERS)} (got {solver!r})")
+    p.qp_mode = BARRIER_SOLVERS[solver]
+    p.ipm_abstol, p.ipm_reltol = float(cfg.get("cvxopt_abstol", 1e-7)), float(cfg.get("cvxopt_reltol", 1e-2))
+    p.ipm_feastol, p.ipm_maxiters = float(cfg.get("cvxopt_feastol", 1e-2)), int(cfg.get("cvxopt_maxiters", 50))
     p.qp_rtol = float(cfg.get("qp_rtol", QP_RTOL))
     p.qp_max_sweeps = int(cfg.get("qp_max_sweeps", QP_MAX_SWEEPS))
     p.collision_variant = COLLISION_VARIANTS[cfg.get("collision_variant", DEFAULT_COLLISION_VARIANT)]
@@ -225,6 +237,9 @@ def make_params(scenario, cfg):
         p.agent_grid = g
         p.prey_grid = _dummy_grid()
         p.keep_theta = 0
+    if p.qp_mode == BARRIER_SOLVERS["cvxopt"] and p.n_agents > CVXOPT_MAX_AGENTS:
+        raise ValueError(f"barrier_solver: cvxopt is built for n_agents <= {CVXOPT_MAX_AGENTS} (its QP is solved in one lane: 2N unknowns, "
+                         f"N(N-1)/2 rows in registers); got {p.n_agents}")
     return p
 
 

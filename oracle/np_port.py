@@ -39,10 +39,17 @@ class Args(object):
 
 
 class ControllerPort(object):  # utilities/controller.py:4-24
-    def __init__(self, type='safe'):
+    def __init__(self, type='safe', family=None):
         self.position_controller = create_si_position_controller()
         self.si_to_uni_dyn, self.uni_to_si_states = create_si_to_uni_mapping()
-        if type == "safe":
+        if family:   # Controller('custom', <one of rps' factories with other arguments>): config keys of the certificate family
+            kw = {"barrier_gain": family.get("barrier_gain", 100), "magnitude_limit": family.get("magnitude_limit", 0.2)}
+            if type == "safe":
+                self.si_barrier_cert = create_single_integrator_barrier_certificate2(
+                    unsafe_barrier_gain=family.get("unsafe_barrier_gain", 1e6), safety_radius=family.get("safety_radius", 0.2), **kw)
+            else:
+                self.si_barrier_cert = create_single_integrator_barrier_certificate(safety_radius=family.get("safety_radius", 0.17), **kw)
+        elif type == "safe":
             self.si_barrier_cert = create_single_integrator_barrier_certificate2(safety_radius=.2)
         elif type == "default":
             self.si_barrier_cert = create_single_integrator_barrier_certificate()
@@ -60,7 +67,8 @@ class RoboEnvPort(object):  # utilities/roboEnv.py:11-121
     def __init__(self, agents, args):
         self.args = args
         self.agents = agents
-        self.controller = ControllerPort(getattr(args, "barrier_certificate", "safe"))
+        family = {k: getattr(args, k) for k in ("safety_radius", "barrier_gain", "unsafe_barrier_gain", "magnitude_limit") if hasattr(args, k)}
+        self.controller = ControllerPort(getattr(args, "barrier_certificate", "safe"), family)
         self.first_run = True
         self.errors = {}
         self.previous_pose = None
@@ -552,4 +560,6 @@ def make_port(scenario, cfg):
     # as tests/golden/ref_harness.py does for the reference run
     import rps.robotarium as _rr
     _rr.COLLISION_VARIANT = cfg.get("collision_variant", "offset")
+    import rps.utilities.barrier_certificates as _bc   # likewise the stand-in for cvxopt below the certificate closures
+    _bc.QP_SOLVER = cfg.get("barrier_solver", "exact")
     return PORTS[scenario](Args(cfg))

@@ -565,12 +565,28 @@ static void ipm_solve(int n, const double *K, const double *rd, double *b) {
 }
 /* xi: the robots' single-integrator points; u: in, the control inputs ALREADY thresholded to the magnitude limit; out, the iterate.
  * Returns the iteration count (cvxopt's `iterations`). */
-static int barrier_qp_ipm_spec(const orc_params *p, int N, const double *xix, const double *xiy, double *ux, double *uy) {
+typedef struct { double abstol, reltol, feas2, r2, gain, ugain; int maxiters, has_unsafe; } ipm_consts;
+/* as_float: the float tier's parameters are binary32 values (what the product's rg_scenario_params carries), widened exactly */
+static ipm_consts ipm_make_consts(const orc_params *p, int as_float) {
+#define IPM_P(v) (as_float ? (double)(float)(v) : (double)(v))
+    ipm_consts k;
+    k.abstol = IPM_P(p->ipm_abstol);
+    k.reltol = IPM_P(p->ipm_reltol);
+    k.feas2 = IPM_P(p->ipm_feastol) * IPM_P(p->ipm_feastol);
+    k.r2 = IPM_P(p->safety_radius) * IPM_P(p->safety_radius);
+    k.gain = IPM_P(p->barrier_gain);
+    k.ugain = IPM_P(p->unsafe_barrier_gain);
+    k.maxiters = p->ipm_maxiters;
+    k.has_unsafe = p->barrier_has_unsafe_gain;
+#undef IPM_P
+    return k;
+}
+static int barrier_qp_ipm_spec(const ipm_consts *kc, int N, const double *xix, const double *xiy, double *ux, double *uy) {
     if (N < 2 || N > ORC_IPM_MAXN) return N < 2 ? 0 : -1; /* no rows: the unconstrained minimiser is the input itself */
     const int n = 2 * N, m = N * (N - 1) / 2;
-    const double ABSTOL = p->ipm_abstol, RELTOL = p->ipm_reltol, FEAS2 = p->ipm_feastol * p->ipm_feastol, STEP = 0.99;
-    const int MAXITERS = p->ipm_maxiters;
-    const double r2 = p->safety_radius * p->safety_radius;
+    const double ABSTOL = kc->abstol, RELTOL = kc->reltol, FEAS2 = kc->feas2, STEP = 0.99;
+    const int MAXITERS = kc->maxiters;
+    const double r2 = kc->r2;
     double ex[ORC_IPM_MAXC], ey[ORC_IPM_MAXC], h[ORC_IPM_MAXC], s[ORC_IPM_MAXC], z[ORC_IPM_MAXC], w4[ORC_IPM_MAXC];
     double rz[ORC_IPM_MAXC], rs[ORC_IPM_MAXC], ds[ORC_IPM_MAXC], dz[ORC_IPM_MAXC], dsdza[ORC_IPM_MAXC];
     double q[ORC_IPM_MAXV], x[ORC_IPM_MAXV], rx[ORC_IPM_MAXV], dx[ORC_IPM_MAXV], rd[ORC_IPM_MAXV], K[ORC_IPM_MAXV * ORC_IPM_MAXV];
@@ -582,7 +598,7 @@ static int barrier_qp_ipm_spec(const orc_params *p, int N, const double *xix, co
                 ex[c] = xix[i] - xix[j];
                 ey[c] = xiy[i] - xiy[j];
                 const double hh = __builtin_fma(ex[c], ex[c], ey[c] * ey[c]) - r2;
-                const double gain = (hh >= 0.0 || !p->barrier_has_unsafe_gain) ? p->barrier_gain : p->unsafe_barrier_gain;
+                const double gain = (hh >= 0.0 || !kc->has_unsafe) ? kc->gain : kc->ugain;
                 h[c] = gain * ((hh * hh) * hh);
                 nh = __builtin_fma(h[c], h[c], nh);
                 w4[c] = 4.0;
@@ -749,7 +765,8 @@ static int FN(barrier_qp_ipm_spec_call)(const orc_params *p, int N, const REAL *
         dux[a] = (double)ux[a];
         duy[a] = (double)uy[a];
     }
-    int it = barrier_qp_ipm_spec(p, N, dxi, dyi, dux, duy);
+    const ipm_consts kc = ipm_make_consts(p, ORC_IS_F32);
+    int it = barrier_qp_ipm_spec(&kc, N, dxi, dyi, dux, duy);
     for (int a = 0; a < N; ++a) {
         ux[a] = (REAL)dux[a];
         uy[a] = (REAL)duy[a];

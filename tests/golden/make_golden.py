@@ -162,6 +162,33 @@ CASES = [
     ("warehouse_n8_no_penalty", "Warehouse", {"n_agents": 8, "penalize_violations": False}, [141], 140, 0.5),
     ("pcp_n5_center_collision", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "collision_variant": "center"},
      [151], 170, 1.0),
+    # round 5 -- other arguments of rps' certificate factories (config keys safety_radius / barrier_gain / unsafe_barrier_gain /
+    # magnitude_limit; the reference's own route: Controller('custom', create_..._certificate2(...)), controller.py:17-18)
+    ("pcp_n5_family", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "safety_radius": 0.25, "barrier_gain": 30.0,
+                                              "unsafe_barrier_gain": 1e5, "magnitude_limit": 0.12}, [161], 120, 0.5),
+    ("warehouse_n6_family_default", "Warehouse", {"barrier_certificate": "default", "safety_radius": 0.22, "barrier_gain": 300.0}, [163], 100, 0.5),
+    # round 5 -- `barrier_solver: cvxopt`: the certificate's QP handed to the restated interior-point `qp` at rps' options
+    # (reltol = feastol = 1e-2, maxiters 50), as the reference's own stack evaluates it (controller.py:13-16,23): ipm_* fixtures
+    ("ipm_pcp_n5", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "barrier_solver": "cvxopt"}, [211, 212, 213], 140, 0.35),
+    ("ipm_pcp_n4_default", "PredatorCapturePrey", {"barrier_solver": "cvxopt"}, [221, 222], 120, 0.35),
+    ("ipm_pcp_n5_random", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "barrier_solver": "cvxopt"}, [231], 170, 1.0),
+    ("ipm_warehouse_n8", "Warehouse", {"n_agents": 8, "barrier_solver": "cvxopt"}, [251], 150, 0.3),
+    ("ipm_warehouse_n6_default", "Warehouse", {"barrier_solver": "cvxopt"}, [261], 130, 0.3),
+    ("ipm_warehouse_n8_random", "Warehouse", {"n_agents": 8, "barrier_solver": "cvxopt"}, [271], 110, 1.0),
+    ("ipm_mt_n4_default", "MaterialTransport", {"barrier_solver": "cvxopt"}, [281], 100, 0.25),
+    ("ipm_mt_n6", "MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25, "barrier_solver": "cvxopt"},
+     [291], 100, 0.25),
+    ("ipm_mt_n6_random", "MaterialTransport", {"n_agents": 6, "n_fast_agents": 3, "n_slow_agents": 3, "start_dist": 0.25,
+                                               "barrier_solver": "cvxopt"}, [295], 80, 1.0),
+    ("ipm_simple_n4_default", "Simple", {"barrier_solver": "cvxopt"}, [301], 110, 0.3),
+    ("ipm_simple_n6_random", "Simple", {"n_agents": 6, "barrier_solver": "cvxopt"}, [305], 110, 1.0),
+    ("ipm_arctic_default", "ArcticTransport", {"barrier_solver": "cvxopt"}, [311, 312], 130, 0.25),
+    ("ipm_pcp_n5_robotarium", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "robotarium": True, "barrier_solver": "cvxopt"},
+     [321], 60, 0.35),
+    ("ipm_pcp_n5_cert_default", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "barrier_certificate": "default",
+                                                        "barrier_solver": "cvxopt"}, [331], 120, 0.35),
+    ("ipm_pcp_n5_family", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "safety_radius": 0.25, "barrier_gain": 30.0,
+                                                  "unsafe_barrier_gain": 1e5, "magnitude_limit": 0.12, "barrier_solver": "cvxopt"}, [341], 100, 0.5),
 ]
 
 
@@ -189,14 +216,20 @@ def run_case(name, scenario, overrides, seeds, steps, eps):
     return recs, np.array(first, dtype=np.uint8), cfg_out
 
 
-def forced_violation_cases():
+def forced_violation_cases(solver="exact"):
     """Hand-placed poses that trip rps' validation (collision / boundary / both) on a later step;
     one clean step is taken first (roboEnv.py:21 initialises its counters to ints, so a
-    violation on the very first validate of a process would raise in the reference)."""
+    violation on the very first validate of a process would raise in the reference).
+    solver = "cvxopt": the same with the interior-point stand-in (ipm_viol_* fixtures, three scenarios)."""
     out = []
-    for scenario, ov in (("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}),
-                         ("Warehouse", {"n_agents": 8}),
-                         ("MaterialTransport", {}), ("Simple", {}), ("ArcticTransport", {})):
+    scenarios = (("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}),
+                 ("Warehouse", {"n_agents": 8}),
+                 ("MaterialTransport", {}), ("Simple", {}), ("ArcticTransport", {}))
+    prefix = ""
+    if solver == "cvxopt":
+        scenarios = tuple((sc, dict(ov, barrier_solver="cvxopt")) for sc, ov in scenarios[:3])
+        prefix = "ipm_"
+    for scenario, ov in scenarios:
         for kind in ("collision", "boundary", "both", "barrier_unsafe", "late_boundary"):
             ov2 = dict(ov)
             ov2["seed"] = 5
@@ -229,7 +262,7 @@ def forced_violation_cases():
                 else:
                     acts[0], acts[1] = 1, 0
             recs.append(rh.step_record(w, scenario, acts))
-            out.append((f"viol_{scenario}_{kind}", scenario, cfg, recs))
+            out.append((f"{prefix}viol_{scenario}_{kind}", scenario, cfg, recs))
     return out
 
 
@@ -257,7 +290,9 @@ def main():
         v = d["viol"]
         print(f"{name}: T={len(recs)} done={int(d['done'].sum())} viol={int((v > 0).sum())} "
               f"reward_sum={d['reward'][:, 0].sum():.3f}")
-    for name, scenario, cfg, recs in ([] if only else forced_violation_cases()):
+    viol = [] if only and "viol" not in only and "ipm_viol" not in only else \
+        (forced_violation_cases() if (not only or "viol" in only) else []) + (forced_violation_cases("cvxopt") if (not only or "ipm_viol" in only) else [])
+    for name, scenario, cfg, recs in viol:
         d = pack(recs)
         d["first_after_reset"] = np.array([1] + [0] * (len(recs) - 1), dtype=np.uint8)
         d["config_json"] = np.array(json.dumps(cfg))

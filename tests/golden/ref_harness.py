@@ -97,8 +97,14 @@ def make_reference_wrapper(scenario, overrides, collision_variant="offset"):
     import random as _pyrandom
     _pyrandom.seed(int(overrides.get("seed", 0)) + 12345)   # ArcticTransport.py:72 draws from Python's `random`
     import rps.robotarium as rr
+    import rps.utilities.barrier_certificates as bc
     rr.COLLISION_VARIANT = collision_variant
     rr._ERRORS.clear()
+    # which solver stands in for cvxopt below rps' certificate closures (oracle/rps_restated): the exact projection (sim_spec_v0's
+    # default) or the restated interior-point `qp` at rps' options -- what the reference's stack itself evaluates
+    solver = overrides.get("barrier_solver", "exact")
+    assert solver in ("exact", "cvxopt"), solver
+    bc.QP_SOLVER = solver
     cfg = load_reference_config(scenario)
     cfg.update({"show_figure_frequency": -1, "enable_logging": False, "save_gif": False,
                 "real_time": False, "robotarium": False})
@@ -112,6 +118,18 @@ def make_reference_wrapper(scenario, overrides, collision_variant="offset"):
             w = Wrapper(scenario, path)
     finally:
         os.unlink(path)
+    family = {k: cfg[k] for k in ("safety_radius", "barrier_gain", "unsafe_barrier_gain", "magnitude_limit") if k in cfg}
+    if family:
+        # a certificate with other arguments: the reference's own route is Controller(type='custom', custom=<closure>)
+        # (utilities/controller.py:17-18), the closure being one of rps' factories called with those arguments
+        from robotarium_gym.utilities.controller import Controller
+        kw = {"barrier_gain": family.get("barrier_gain", 100), "magnitude_limit": family.get("magnitude_limit", 0.2)}
+        if cfg.get("barrier_certificate", "safe") == "safe":
+            cert = bc.create_single_integrator_barrier_certificate2(unsafe_barrier_gain=family.get("unsafe_barrier_gain", 1e6),
+                                                                    safety_radius=family.get("safety_radius", 0.2), **kw)
+        else:
+            cert = bc.create_single_integrator_barrier_certificate(safety_radius=family.get("safety_radius", 0.17), **kw)
+        w.env.env.controller = Controller("custom", custom=cert)
     return w, cfg
 
 

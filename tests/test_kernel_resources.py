@@ -133,9 +133,23 @@ def test_shipped_resources_lane_group(shipped):
     """The lane-group step kernels (rg_step form) of the benchmark agent counts: no spilled VGPR, three waves per SIMD."""
     for scn, n in ((0, 5), (1, 8), (2, 6), (0, 4)):   # step_kernel<SCN, GW, OBS_ONLY, NT, ROLLOUT, ...>: NT = N for groups of 8, 0 otherwise
         gw, nt = (4, 0) if n <= 4 else (8, n)
-        hits = {k: r for k, r in _res(shipped, f"2rg11step_kernelILi{scn}ELi{gw}ELb0ELi{nt}ELb0E").items()}
+        hits = {k: r for k, r in _res(shipped, f"2rg11step_kernelILi{scn}ELi{gw}ELb0ELi{nt}ELb0E").items()
+                if "ELi1EEEvNS" not in k}                   # (exact-projection mode; the interior-point instantiations below)
+        assert hits
         for k, r in hits.items():
             assert r["spill"] == 0 and r["scratch"] <= 128 and r["occupancy"] >= 3, (k, r)
+
+
+def test_shipped_interior_point_kernels(shipped):
+    """`barrier_solver: cvxopt` (RG_QP_CVXOPT): its step kernels are separate instantiations (last template argument 1) that call the
+    out-of-line iteration of csrc/ipm_qp.h -- one body per agent count 2..8 and translation unit, compiled for one wave per SIMD
+    with the accumulation registers as spill space -- and the exact-mode kernels carry none of it."""
+    ipm_kernels = {k: r["resources"] for k, r in shipped.items() if "2rg11step_kernelI" in k and "ELi1EEEvNS" in k}
+    assert len(ipm_kernels) >= 2 * (4 * 2 + 1)              # single-step (+ gymma) for GW 4 / 8 x four scenarios + ArcticTransport
+    for k, r in ipm_kernels.items():
+        assert r["occupancy"] == 1 and r["vgpr"] == 512, (k, r)
+    bodies = [k for k in shipped if "3ipm8solve_qpI" in k]
+    assert len(bodies) >= 7, bodies
 
 
 def test_shipped_actor_kernels_keep_their_weight_ring_and_two_tiles_per_cu():
@@ -214,6 +228,7 @@ def test_dot_hazard_scan_fails_when_the_s_nop_is_removed(tmp_path):
     import isa_scan
     inc = tmp_path / "csrc"
     inc.mkdir()
+    shutil.copytree(os.path.join(CSRC, "probes"), str(inc / "probes"))
     for h in os.listdir(CSRC):
         if h.endswith(".h"):
             text = open(os.path.join(CSRC, h)).read().replace('#include "../../include/robogym.h"', f'#include "{os.path.join(ROOT, "include", "robogym.h")}"')
