@@ -182,7 +182,6 @@ struct alignas(16) Lds {
             float prey[WAVE / GW][RG_MAX_PREY * 2];  // the env's prey block (PredatorCapturePrey)
             float own[WAVE][8];                      // each agent's own-observation row (<= 6 floats)
             float ax[WAVE], ay[WAVE];                // MaterialTransport sequential replay / reward sum
-            float4 qp[WAVE];                         // RG_QP_CVXOPT: each agent's (xi, uhat) in, the iterate out (ipm_qp.h)
             int aload[WAVE];
             uint8_t grid[WAVE / GW][RG_ARCTIC_ROWS * RG_ARCTIC_COLS];  // ArcticTransport terrain of the env
         };

@@ -51,11 +51,11 @@ static_assert(CHUNK >= 1 && CHUNK <= 5, "the sparse collision pre-test covers su
 // utilities/controller.py:20-24 over the restated rps closures,
 // followed by Robotarium.set_velocities' clipping.  Called in wave-uniform control flow.
 // QPM: how the certificate's QP is evaluated (include/robogym.h RG_QP_*): 0 the exact projection by the Hildreth sweeps below,
-// 1 cvxopt's interior-point iterate (ipm_qp.h; qp = the wave's LDS records, one per lane).
-template <int GW, int QPM = 0>
+// 1 cvxopt's interior-point iterate (ipm_qp.h; qp = the wave's LDS of that mode: one record per lane, one workspace per env).
+template <int GW, int QPM = 0, typename QpLds = void>
 __device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, int N, int ag, bool lane_ok,
                                           bool upd, float x, float y, float c, float s, float gx, float gy, float &v,
-                                          float &w, float4 *qp RG_CTRL_TICKS_PARAM) {
+                                          float &w, QpLds *qp RG_CTRL_TICKS_PARAM) {
     RG_CTRL_BEGIN(x, y, c, s)
     // a4 uni_to_si_states, a5 si_position_controller (gain 1, |dxi| <= 0.15)
     const float xix = x + k.pd * c, xiy = y + k.pd * s;
@@ -80,12 +80,12 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
             }
         }
         const int lane_ = threadIdx.x;
-        qp[lane_] = make_float4(xix, xiy, ux, uy);
+        qp->rec[lane_] = make_float4(xix, xiy, ux, uy);
         __syncthreads();   // (one wave per workgroup: the records are visible)
         int iters = 0;
-        if (upd) iters = ipm::solve_qp_n(N, ipm::make_consts(p), qp + (lane_ & ~(GW - 1)));
+        if (upd) iters = ipm::solve_qp_n<GW>(N, ipm::make_consts(p), qp->rec + (lane_ & ~(GW - 1)), qp->ws[lane_ / GW], ag);
         __syncthreads();
-        const float4 r = qp[lane_];
+        const float4 r = qp->rec[lane_];
         ux = r.z;
         uy = r.w;
         RG_CTRL_TICK(1);
@@ -312,8 +312,8 @@ __device__ __forceinline__ void write_neighbour_obs(Lds<GW> &lds, int N, int Knb
 // the launch costs the MEAN wavefront, and drawing ahead moves the sampler's work without removing any.
 // GYM: the gymma block of rg_step_io (gym's TimeLimit + reductions) is compiled in.  Its own instantiations (generic agent
 // count, single-step launch): the benchmark kernels carry none of it.
-template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD, bool GYM, int QPM = 0>
-__device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, const StepView &sv) {
+template <int SCN, int GW, bool OBS_ONLY, int NT, bool AHEAD, bool GYM, int QPM = 0, typename QpLds = void>
+__device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, const StepView &sv, QpLds *qp_lds = nullptr) {
     constexpr int EPW = WAVE / GW;  // envs per wave
     RG_STAMPS_BEGIN()
     const rg_scenario_params &p = a.p;
@@ -568,7 +568,7 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
         for (int it0 = 0; it0 < U; it0 += period) {
             const int n = (U - it0) < period ? (U - it0) : period;
             RG_HEADING_SINCOS(th, s, c);
-            const int sw = controller<GW, QPM>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w, lds.qp RG_CTRL_TICKS_ARG);
+            const int sw = controller<GW, QPM>(p, k, N, ag, lane_ok, env_ok & !dead, x, y, c, s, gx, gy, v, w, qp_lds RG_CTRL_TICKS_ARG);
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
             const float dtv = k.dt * v, dtw = k.dt * w;
             float sd, cd;
@@ -1293,12 +1293,23 @@ template <int SCN, int GW, bool OBS_ONLY, int NT, bool ROLLOUT, bool GYM = false
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ Lds<GW> lds;
     const int N = NT > 0 ? NT : a.p.n_agents;
-    if constexpr (!ROLLOUT) {
-        step_once<SCN, GW, OBS_ONLY, NT, true, GYM, QPM>(a, lds, step_view(a, 0, N, a.p.obs_dim));
+    if constexpr (QPM == RG_QP_CVXOPT) {
+        static_assert(GW == 4 || GW == 8, "the interior-point mode admits n_agents <= 8");
+        __shared__ ipm::GroupLds<GW> qp_lds;   // records + one workspace per env (ipm_qp.h): these instantiations only
+        if constexpr (!ROLLOUT) {
+            step_once<SCN, GW, OBS_ONLY, NT, true, GYM, QPM>(a, lds, step_view(a, 0, N, a.p.obs_dim), &qp_lds);
+        } else {
+            for (int t = 0; t < a.num_steps; ++t) {
+                if (t) __syncthreads();
+                step_once<SCN, GW, OBS_ONLY, NT, false, false, QPM>(a, lds, step_view(a, t, N, a.p.obs_dim), &qp_lds);
+            }
+        }
+    } else if constexpr (!ROLLOUT) {
+        step_once<SCN, GW, OBS_ONLY, NT, true, GYM, QPM>(a, lds, step_view(a, 0, N, a.p.obs_dim), static_cast<void *>(nullptr));
     } else {
         for (int t = 0; t < a.num_steps; ++t) {
             if (t) __syncthreads();
-            step_once<SCN, GW, OBS_ONLY, NT, false, false, QPM>(a, lds, step_view(a, t, N, a.p.obs_dim));
+            step_once<SCN, GW, OBS_ONLY, NT, false, false, QPM>(a, lds, step_view(a, t, N, a.p.obs_dim), static_cast<void *>(nullptr));
         }
     }
 }

@@ -502,6 +502,8 @@ static int FN(barrier_qp_ipm)(const orc_params *p, int N, const REAL *xix, const
  *     backward with fma chains in ascending index order;
  *   - ONE reciprocal per row per iteration (1 / s_c) and one per pivot; the step to the boundary max(-ds/s, -dz/z) is found by
  *     cross-multiplied comparisons (a/b > c/d  <=>  a d > c b, all denominators positive) and divided once;
+ *   - no division instruction: every reciprocal is ipm_rcp below (exponent-field seed + five Newton steps: deterministic, within
+ *     two ulp; arguments are positive by construction -- s_c, z_c stay inside the cone, the pivots of 2I + PSD are >= 2);
  *   - no square root anywhere: the residual tests compare squared norms (|r| <= tol max(1, |r0|)  <=>  r.r <= tol^2 max(1, r0.r0));
  *   - sums run in ascending index order, left to right.
  * Like everything below the reference's own layers this is PARITY UNPINNED against real cvxopt; against barrier_qp_ipm it differs by
@@ -509,6 +511,20 @@ static int FN(barrier_qp_ipm)(const orc_params *p, int N, const REAL *xix, const
 #define ORC_IPM_MAXN 8
 #define ORC_IPM_MAXV (2 * ORC_IPM_MAXN)
 #define ORC_IPM_MAXC (ORC_IPM_MAXN * (ORC_IPM_MAXN - 1) / 2)
+/* 1 / v for v > 0 without the divider: a seed from the exponent field (relative error < 12.5 %) and five Newton steps
+ * r <- r + r (1 - v r), each two fmas: the error squares every step (1.6e-2, 2.4e-4, 6e-8, 3.6e-15, then rounding), so the result
+ * is the reciprocal to within two units in the last place -- and the SAME BITS on every IEEE machine, which the hardware's
+ * v_rcp_f64 is not.  A correctly rounded binary64 division costs ~30 dependent instructions on gfx950 (v_div_scale / v_rcp /
+ * refinement / v_div_fmas through VCC, so independent divisions do not interleave); this costs 12 that do.  (ipm_spec_v0 only.) */
+static inline double ipm_rcp(double v) {
+    uint64_t b;
+    __builtin_memcpy(&b, &v, 8);
+    b = 0x7FDE6238DA3C2118ull - b;
+    double r;
+    __builtin_memcpy(&r, &b, 8);
+    for (int t = 0; t < 5; ++t) r = __builtin_fma(r, __builtin_fma(-v, r, 1.0), r);
+    return r;
+}
 /* K (lower triangle, row-major n x n storage) <- 2I + sum_c w_c a_c a_c', a_c = -2 e_c at robot i, +2 e_c at robot j: with
  * W = 4 w the blocks are +-W e e' */
 static void ipm_assemble(int N, const double *ex, const double *ey, const double *w4, double *K) {
@@ -542,7 +558,7 @@ static void ipm_ldl(int n, double *K, double *rd) {
             d = __builtin_fma(-K[j * n + k], v[k], d);
         }
         K[j * n + j] = d;
-        rd[j] = 1.0 / d;
+        rd[j] = ipm_rcp(d);
         for (int i = j + 1; i < n; ++i) {
             double t = K[i * n + j];
             for (int k = 0; k < j; ++k) t = __builtin_fma(-K[i * n + k], v[k], t);
@@ -686,12 +702,12 @@ static int barrier_qp_ipm_spec(const ipm_consts *kc, int N, const double *xix, c
         if ((nrz <= resz0sq && nrx <= resx0sq && (gap <= ABSTOL || rel_ok)) || iters == MAXITERS) break;
         /* scaling and the KKT matrix of this iteration */
         for (int c = 0; c < m; ++c) {
-            rs[c] = 1.0 / s[c];
+            rs[c] = ipm_rcp(s[c]);
             w4[c] = 4.0 * (z[c] * rs[c]);
         }
         ipm_assemble(N, ex, ey, w4, K);
         ipm_ldl(n, K, rd);
-        const double mu = gap / (double)m;
+        const double mu = gap * (1.0 / (double)m);
         double sigmamu = 0.0, step = 1.0;
         for (int pass = 0; pass < 2; ++pass) {
             /* rc = -s o z + sigma mu [- dsa o dza];  dx = K^-1 (-rx - G'[(rc + z o rz) / s]) */
@@ -725,13 +741,13 @@ static int barrier_qp_ipm_spec(const ipm_consts *kc, int N, const double *xix, c
                     }
             }
             if (pass == 0) {
-                step = tn > td ? td / tn : 1.0;                  /* min(1, 1 / t);  t == 0 -> 1 */
-                double sg = __builtin_fma(dsdz / gap, step * step, 1.0 - step);
+                step = tn > td ? td * ipm_rcp(tn) : 1.0;         /* min(1, 1 / t);  t == 0 -> 1 */
+                double sg = __builtin_fma(dsdz * ipm_rcp(gap), step * step, 1.0 - step);
                 sg = sg < 0.0 ? 0.0 : sg > 1.0 ? 1.0 : sg;
                 sigmamu = ((sg * sg) * sg) * mu;
                 for (int c = 0; c < m; ++c) dsdza[c] = ds[c] * dz[c];
             } else {
-                step = STEP * td < tn ? (STEP * td) / tn : 1.0;   /* min(1, 0.99 / t) */
+                step = STEP * td < tn ? (STEP * td) * ipm_rcp(tn) : 1.0;   /* min(1, 0.99 / t) */
             }
         }
         for (int k = 0; k < n; ++k) x[k] = __builtin_fma(step, dx[k], x[k]);
@@ -1374,6 +1390,26 @@ void FN(orc_sincos)(int n, const REAL *t, REAL *s, REAL *c) {
 void FN(orc_atan2)(int n, const REAL *y, const REAL *x, REAL *o) {
     for (int i = 0; i < n; ++i) o[i] = ATAN2(y[i], x[i]);
 }
+#if ORC_IS_F32
+/* tests: ipm_spec_v0 on binary32 records (xi_x, xi_y, uhat_x, uhat_y) x N, exactly what the kernels' LDS records hold; the iterate
+ * replaces uhat.  Returns the iteration count. */
+int orc_ipm_spec_f32io(const orc_params *p, int N, float *io) {
+    double xi[ORC_MAXN], yi[ORC_MAXN], ux[ORC_MAXN], uy[ORC_MAXN];
+    for (int a = 0; a < N; ++a) {
+        xi[a] = io[4 * a];
+        yi[a] = io[4 * a + 1];
+        ux[a] = io[4 * a + 2];
+        uy[a] = io[4 * a + 3];
+    }
+    const ipm_consts kc = ipm_make_consts(p, 1);
+    int it = barrier_qp_ipm_spec(&kc, N, xi, yi, ux, uy);
+    for (int a = 0; a < N; ++a) {
+        io[4 * a + 2] = (float)ux[a];
+        io[4 * a + 3] = (float)uy[a];
+    }
+    return it;
+}
+#endif
 int FN(orc_controller)(const orc_params *p, const REAL *poses /*3xN*/, const REAL *goals /*2xN*/, REAL *dxu /*2xN*/) {
     int N = p->n_agents;
     REAL cs[ORC_MAXN], ss[ORC_MAXN];

@@ -106,6 +106,21 @@ def test_exec_prologue_check_sees_the_failing_pattern():
     no_branch = prog(("s_and_saveexec_b64", "s[4:5], vcc", None), ("v_mul_f32_e32", "v1, v2, v3", None),   # short `then`, no skip branch
                      ("s_or_b64", "exec, exec, s[4:5]", None), ("s_endpgm", "", None))
     assert exec_prologue(no_branch) == []
+    # round 5: the BODY of an `else` (SI_ELSE lowered as s_or_saveexec / copies / s_xor) that is one phi copy long and falls into
+    # the join -- entered only from `s_xor_b64 exec, exec, mask`, so its v_mov is meant for the else lanes (csrc/ipm_qp.h's loop exit)
+    lbl = 0x100 + 4 * 8
+    else_body = prog(("s_and_saveexec_b64", "s[12:13], s[8:9]", None), ("s_xor_b64", "s[8:9], exec, s[12:13]", None), ("s_cbranch_execz", "4", 0x100 + 4 * 6),
+                     ("s_or_saveexec_b64", "s[4:5], s[8:9]", None), ("v_mov_b32_e32", "v4, v13", None), ("s_xor_b64", "exec, exec, s[4:5]", None),
+                     ("s_or_saveexec_b64", "s[4:5], s[8:9]", None) if False else ("s_nop", "0", None), ("s_xor_b64", "exec, exec, s[4:5]", None),
+                     ("v_mov_b32_e32", "v4, v12", None),              # <- label: the else side of the phi
+                     ("s_or_b64", "exec, exec, s[4:5]", None), ("s_endpgm", "", None))
+    else_body[2].target = lbl    # (the skip branch lands on the else body, straight after an s_xor -- see below)
+    else_body[2].op = "s_branch"
+    else_body[1] = Inst(else_body[1].addr, "s_xor_b64", "exec, exec, s[4:5]", None)
+    assert exec_prologue(else_body) == []
+    # ... but the same block reached from anywhere else (here: a conditional branch not preceded by the s_xor) is still a finding
+    else_body[1] = Inst(else_body[1].addr, "s_mov_b64", "s[20:21], exec", None)
+    assert len(exec_prologue(else_body)) == 1
 
 
 def _res(shipped, fragment):
@@ -147,7 +162,7 @@ def test_shipped_interior_point_kernels(shipped):
     ipm_kernels = {k: r["resources"] for k, r in shipped.items() if "2rg11step_kernelI" in k and "ELi1EEEvNS" in k}
     assert len(ipm_kernels) >= 2 * (4 * 2 + 1)              # single-step (+ gymma) for GW 4 / 8 x four scenarios + ArcticTransport
     for k, r in ipm_kernels.items():
-        assert r["occupancy"] == 1 and r["vgpr"] == 512, (k, r)
+        assert r["occupancy"] == 1 and r["vgpr"] > 256 and r["lds"] <= 40 * 1024, (k, r)   # (accumulation registers in use: one wave per SIMD)
     bodies = [k for k in shipped if "3ipm8solve_qpI" in k]
     assert len(bodies) >= 7, bodies
 

@@ -151,6 +151,30 @@ def _is_then_entry(insts, index_of, label_addr, mask):
     return bool(preds) and all(insts[q].op == "s_cbranch_execnz" and saves_mask_before(q) for q in preds)
 
 
+def _is_else_body(insts, index_of, label_addr, mask):
+    """The block at `label_addr`, which ends in `s_or_b64 exec, exec, mask`, is the BODY of an `else` whose head was lowered as
+    `s_or_saveexec_b64 mask, sX ; <copies for both sides> ; s_xor_b64 exec, exec, mask` (or as the single `s_andn2_saveexec_b64 mask, sX`):
+    every way into it -- the fall-through and every branch -- comes straight from that instruction.  Its instructions are MEANT to run for the else lanes only
+    (typically the else side's value of a phi, one v_mov) and the restore that follows is the join: not the defect."""
+    k = index_of.get(label_addr)
+    if k is None or k == 0:
+        return False
+
+    def is_xor(it):   # the second half of SI_ELSE: exec <- the else lanes, in either of the two forms the compiler emits
+        a = it.args.replace(" ", "")
+        return (it.op == "s_xor_b64" and a == f"exec,exec,{mask}".replace(" ", "")) or \
+               (it.op == "s_andn2_saveexec_b64" and a.startswith(mask.replace(" ", "") + ","))
+    ways = []
+    if not insts[k - 1].op.startswith(("s_branch", "s_endpgm", "s_setpc")):
+        ways.append(insts[k - 1])                        # fall-through
+    for q, it in enumerate(insts):
+        if it.target == label_addr:
+            if it.op != "s_branch" or q == 0:
+                return False
+            ways.append(insts[q - 1])
+    return bool(ways) and all(is_xor(w) for w in ways)
+
+
 def exec_prologue(insts):
     """Vector instructions between a branch-target label and the `s_or_b64 exec, exec, sN` that restores a mask saved in
     another block (= the SI_END_CF of a divergent if / loop whose join block this is).  -> [problem strings]."""
@@ -188,6 +212,8 @@ def exec_prologue(insts):
                 at_label = True
         if at_label and seen and _is_then_entry(insts, index_of, insts[j].addr, mask):
             continue        # an out-of-line `then` body (entered only by `s_and_saveexec mask; s_cbranch_execnz`) ending in its own copy of the join
+        if at_label and seen and it.op == "s_or_b64" and _is_else_body(insts, index_of, insts[j].addr, mask):
+            continue        # the body of an `else` (entered only from `s_xor_b64 exec, exec, mask`) falling into the join
         if at_label and seen:
             bad.append(f"{len(seen)} vector instruction(s) run under the incoming exec mask before `{it!r}` restores it, e.g. `{seen[-1]!r}`")
     return bad
