@@ -520,7 +520,7 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
 
 // runtime agent count -> the out-of-line body (N = 1: no rows, the unconstrained minimiser is the thresholded input itself).
 // GW: the caller's lane-group width.  N <= 4 (groups of 4; also one lane per env, N <= 5): every lane runs the whole iteration
-// with the rows in registers -- measured faster than sharing them through LDS up to N = 4 (tools/ubench/ipm_bench.py: 5.5 k
+// with the rows in registers -- measured faster than sharing them through LDS up to N = 4 (tests/ipm_bench.py: 5.5 k
 // against 7.4 k cycles per iteration at N = 4); N = 5 .. 8 (groups of 8): rows in LDS, row phases spread over the 8 lanes.
 template <int GW>
 __device__ __forceinline__ int solve_qp_n(int N, const Consts &k, float4 *io, double *ws, int sub) {

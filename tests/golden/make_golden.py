@@ -184,7 +184,7 @@ CASES = [
     ("ipm_simple_n6_random", "Simple", {"n_agents": 6, "barrier_solver": "cvxopt"}, [305], 110, 1.0),
     ("ipm_arctic_default", "ArcticTransport", {"barrier_solver": "cvxopt"}, [311, 312], 130, 0.25),
     ("ipm_pcp_n5_robotarium", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "robotarium": True, "barrier_solver": "cvxopt"},
-     [321], 60, 0.35),
+     [321], 90, 0.35),
     ("ipm_pcp_n5_cert_default", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "barrier_certificate": "default",
                                                         "barrier_solver": "cvxopt"}, [331], 120, 0.35),
     ("ipm_pcp_n5_family", "PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "safety_radius": 0.25, "barrier_gain": 30.0,

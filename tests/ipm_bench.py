@@ -3,7 +3,7 @@
 (the lane-group kernel's usage) and one per lane (thread-per-env), checked bit for bit against the CPU twin
 (oracle_core.h barrier_qp_ipm_spec through orc_ipm_spec_f32io).  Build: see tools/ubench/ipm_bench.hip.
 
-    python tools/ubench/ipm_bench.py [--lib tools/ubench/libipm_bench.so] [--inst 1024]
+    python tests/ipm_bench.py [--lib tools/ubench/libipm_bench.so] [--inst 1024]
 """
 import argparse
 import ctypes as C
@@ -14,11 +14,11 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from marbler_amd import load_config, make_params  # noqa: E402
-from oracle import c_oracle  # noqa: E402  (a measurement tool under tools/ubench: the oracle is its checker)
+from oracle import c_oracle  # noqa: E402  (lives under tests/: the oracle is its checker)
 
 
 def draw_instances(N, count, rng, close):

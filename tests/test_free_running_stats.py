@@ -60,7 +60,7 @@ def test_restated_interior_point_method_converges_to_the_exact_projection(oracle
     projection the Hildreth sweeps (and SciPy's NNLS, test_oracle_spec.py) compute -- and at the reference's 1e-2 it does
     not: the iterate sits up to several mm/s (median 1 mm/s on coupled configurations) inside the feasible set."""
     from helpers import golden_files, load_golden
-    g, scenario, cfg = load_golden([p for p in golden_files() if p.endswith("pcp_n5.npz")][0])
+    g, scenario, cfg = load_golden([p for p in golden_files() if p.endswith("/pcp_n5.npz")][0])
     rng = np.random.RandomState(3)
     tight, loose = [], []
     for trial in range(300):

@@ -59,7 +59,7 @@ def _exact_qp(uhat, x, r2, safe):
 def test_barrier_qp_is_the_exact_projection(cert, oracle_lib):
     """Hildreth sweeps (float64 tier) against the active-set solution, on configurations that keep
     several coupled constraints active; float32 tier against float64."""
-    g, scenario, cfg = load_golden([p for p in golden_files() if p.endswith("pcp_n5.npz")][0])
+    g, scenario, cfg = load_golden([p for p in golden_files() if p.endswith("/pcp_n5.npz")][0])
     cfg = dict(cfg, barrier_certificate=cert)
     r = 0.2 if cert == "safe" else 0.17
     rng = np.random.RandomState(3)
@@ -135,3 +135,37 @@ def test_parity_report_covers_every_fixture_under_the_stated_tolerance():
         assert m["max_qp_sweeps"] < 40, name
     # MaterialTransport (74 sub-steps, 5 QPs per step) holds the same bar as the 29-sub-step scenarios
     assert max(m["max_xy"] for n, m in rep["fixtures"].items() if m["update_frequency"] == 74) <= 1e-5
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_heading_error_is_attributed_fixture_by_fixture(path, oracle_lib):
+    """Where the heading's miss of north_star's 1e-5 comes from (tests/parity.py THETA_VS_CONTROL_BOUNDS).  The control is float64
+    arithmetic from the float32-ROUNDED pre-state -- the best a float32-state engine can do; the float32 spec (= the kernels) is
+    held against it on the same rounded input: the arithmetic's own share stays inside the committed bound of the fixture's class,
+    and the record in PARITY_REPORT.json is current.  In the barrier_unsafe class (the 1.1e-4) the control alone shows the
+    whole error: rounding the stored state, not the kernel's arithmetic."""
+    import os
+    import parity
+    g, scenario, cfg = load_golden(path)
+    name = os.path.basename(path)[:-4]
+    spec = oracle_from_state(oracle_lib, scenario, cfg, pre_state(g), np.float32)
+    spec.step(g["actions"])
+    ctl = parity.control_run(oracle_lib, scenario, cfg, pre_state(g), g["actions"])
+    att = parity.theta_attribution(spec.poses, ctl.poses, g["post_poses"])
+    cls = parity.theta_class(name, cfg)
+    assert att["theta_vs_control"] <= dict(parity.THETA_VS_CONTROL_BOUNDS)[cls], (name, att)
+    rep = parity.load_report()["fixtures"][name]
+    assert abs(att["theta_control"] - rep["theta_control"]) < 1e-12 and abs(att["theta_vs_control"] - rep["theta_vs_control"]) < 1e-12, \
+        "PARITY_REPORT.json is stale: python tests/parity.py --write"
+    if cls == "barrier_unsafe" and rep["max_theta"] > 1e-5:
+        assert att["theta_control"] >= 0.9 * rep["max_theta"], (name, att, rep["max_theta"])
+
+
+def test_heading_attribution_summary():
+    """The summary the docs quote: how many fixtures miss 1e-5 on headings, and how many of those a float64 engine fed the same
+    float32 state would miss as well."""
+    import parity
+    s = parity.load_report()["theta_summary"]
+    assert s["spec_vs_reference_over_1e5"] >= s["control_vs_reference_over_1e5"] >= 10     # the control misses it too: not a kernel property
+    assert s["spec_vs_control_over_1e5"] <= 10 and len(s["arithmetic_dominated"]) <= 3
+    assert len([n for n in s["input_rounding_alone"] if "barrier_unsafe" in n]) >= 6

@@ -1,6 +1,6 @@
 // ipm_bench.hip -- csrc/ipm_qp.h alone (diagnostic, not shipped): one QP per LANE GROUP of 8 (the lane-group kernel's usage: every
 // lane of a group runs the same iteration on its env's LDS records) or one per LANE (the thread-per-env usage), timed with
-// s_memtime per wave.  Driver: tools/ubench/ipm_bench.py (instances drawn like tests/test_ipm_spec.py, results checked against
+// s_memtime per wave.  Driver: tests/ipm_bench.py (under tests/ because it checks against the CPU oracle) (instances drawn like tests/test_ipm_spec.py, results checked against
 // the CPU twin bit for bit).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I marbler_amd/csrc -shared -fPIC -o tools/ubench/libipm_bench.so tools/ubench/ipm_bench.hip
 #include "ipm_qp.h"
