@@ -171,6 +171,10 @@ typedef struct rg_step_io {
                               reset in the same launch, and a truncated episode is booked in the statistics like a finished one */
     float *reward_sum;     /* [E] out: the sum of the agents' rewards in agent order */
     int32_t time_limit;    /* TimeLimit's max_episode_steps (> 0) */
+    int32_t zero_obs_on_end; /* (with the gymma block) nonzero: the observation rows of an env that ENDS in this step are written as
+                              zeros -- gymma users see the reset observation (what the reference's reset() returns,
+                              PredatorCapturePrey.py:136) as the next observation of an episode that just ended; `obs` may then
+                              point straight into the trainer's [T + 1][E][N][D] batch, slot t + 1 */
 } rg_step_io;
 
 typedef struct rg_handle rg_handle;

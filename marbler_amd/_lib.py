@@ -70,7 +70,7 @@ class RgStepIO(C.Structure):
                 ("dist_travelled", C.c_void_p), ("violation", C.c_void_p), ("remaining", C.c_void_p),
                 ("qp_sweeps", C.c_void_p),
                 ("elapsed", C.c_void_p), ("truncated", C.c_void_p), ("ended", C.c_void_p), ("reward_sum", C.c_void_p),
-                ("time_limit", C.c_int32)]
+                ("time_limit", C.c_int32), ("zero_obs_on_end", C.c_int32)]
 
 
 class RgActorWeights(C.Structure):

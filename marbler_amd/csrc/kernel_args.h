@@ -119,6 +119,7 @@ __host__ __device__ inline StepView step_view(const KernelArgs &a, int k, int n_
     v.io.ended = a.io.ended ? a.io.ended + e : nullptr;
     v.io.reward_sum = a.io.reward_sum ? a.io.reward_sum + e : nullptr;
     v.io.time_limit = a.io.time_limit;
+    v.io.zero_obs_on_end = a.io.zero_obs_on_end;
     return v;
 }
 // thread-per-env step kernel (robogym_tpe.hip): same results, chosen by the host for large batches

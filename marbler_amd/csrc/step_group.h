@@ -1214,6 +1214,13 @@ __device__ __forceinline__ void step_once(const KernelArgs &a, Lds<GW> &lds, con
                 sv.io.remaining[e] = remaining;
                 if (sv.io.qp_sweeps) sv.io.qp_sweeps[e] = max_sweeps;
             }
+            if constexpr (GYM) {
+                // rg_step_io.zero_obs_on_end: an env that ends hands the trainer the reset observation (zeros).  This lane wrote
+                // its agent's row above (its own block and its neighbours' slots); the same lane's later stores win.
+                if (sv.io.zero_obs_on_end && ended) {
+                    for (int c = 0; c < D; ++c) obs_row[c] = 0.0f;
+                }
+            }
         }
         RG_STAMP(5);  // outputs stored
         // ---- fused auto-reset of finished envs (scenario.reset(); ~1 env in 70 per step)

@@ -1004,6 +1004,12 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
             sv.io.truncated[e] = trunc ? 1 : 0;
             sv.io.ended[e] = (done | trunc) ? 1 : 0;
             sv.io.reward_sum[e] = rsum;
+            // rg_step_io.zero_obs_on_end: an env that ends hands the trainer the reset observation (zeros).  Its rows were
+            // stored above (by this wave: staged through LDS or written by this lane); this wave's later stores win.
+            if (sv.io.zero_obs_on_end && (done | trunc)) {
+                float *rows = sv.io.obs + sg.e * N * p.obs_dim;
+                for (int c = 0; c < N * p.obs_dim; ++c) rows[c] = 0.0f;
+            }
         }
         if (stats) {  // misc.py:178-185
             float ret = st_ret + (p.shared_reward ? reward[0] : rsum);

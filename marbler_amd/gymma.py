@@ -252,26 +252,52 @@ class BatchedRunner(object):
 
     @torch.no_grad()
     def run(self, T):
+        """With the fused env step and the fused actor a time step is TWO launches: the actor reads the previous step's
+        episode-end flags and observation straight from the batch and writes its greedy actions into it; the env step reads
+        those actions and writes the next observation (zeros for an env that ended: the reset observation), the summed reward
+        and the episode-end flags into the batch (VecRobotariumEnv.step_into).  `state` is a view of `obs` ([E, N * D] of the
+        same memory: gymma's state IS the concatenated observations); `episode_start` is filled once per call."""
         v, env, dev = self.venv, self.venv.env, self.venv.env.device
         E, N, D, A = v.E, v.n_agents, v.obs_size, v.n_actions
-        out = {"obs": torch.empty(T + 1, E, N, D, device=dev), "state": torch.empty(T + 1, E, N * D, device=dev),
+        out = {"obs": torch.empty(T + 1, E, N, D, device=dev),
                "avail_actions": torch.ones(T + 1, E, N, A, dtype=torch.int32, device=dev),
                "actions": torch.empty(T, E, N, dtype=torch.int32, device=dev),
                "reward": torch.empty(T, E, device=dev), "terminated": torch.empty(T, E, dtype=torch.bool, device=dev),
                "episode_start": torch.empty(T, E, dtype=torch.bool, device=dev)}
         fused = self.actor.fused_supported()
         eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
-        # With the fused step (one launch: env step + TimeLimit + reductions) and the fused actor, a time step is seven
-        # launches: the three outputs are written where EPyMARL wants them (no intermediate tensors), the actor reads the
-        # episode-end flags of the previous step in place and writes its greedy actions into the batch.
         direct = fused and v.fused
+        if direct:
+            out["state"] = out["obs"].view(T + 1, E, N * D)
+            out["obs"][0] = v.get_obs()            # zeros right after a reset, like the reference's reset()
+            out["episode_start"][0] = self._restart.view(torch.bool)
+            term_u8 = out["terminated"].view(torch.uint8)
+            env._sync_stream()
+            for t in range(T):
+                obs = out["obs"][t]
+                restart = self._restart if t == 0 else term_u8[t - 1]
+                greedy = out["actions"][t] if self.epsilon <= 0.0 else None
+                _, greedy = self.actor.forward_fused(obs, self.hidden, append_agent_id=self.obs_agent_id, restart=restart,
+                                                     q_out=self._q, actions_out=greedy)
+                if self.epsilon > 0.0:
+                    explore = torch.rand(E, N, generator=self.gen, device=dev) < self.epsilon
+                    rnd = torch.randint(0, A, (E, N), generator=self.gen, device=dev, dtype=torch.int32)
+                    torch.where(explore, rnd, greedy, out=out["actions"][t])
+                rc = env.step_into(out["actions"][t].data_ptr(), out["obs"][t + 1].data_ptr(), out["reward"][t].data_ptr(),
+                                   term_u8[t].data_ptr())
+                if rc != 0:
+                    from . import _lib
+                    _lib.check(rc, "rg_step")
+            if T > 1:
+                out["episode_start"][1:] = out["terminated"][:-1]
+            # the wrapper's own view of "the current observation" and of which envs just restarted, for whoever steps next
+            self._restart = term_u8[T - 1].clone()
+            v._obs, v._ended = out["obs"][T].clone(), out["terminated"][T - 1].clone()
+            return out
+        out["state"] = torch.empty(T + 1, E, N * D, device=dev)
         for t in range(T):
-            if direct and v._obs is None:          # the next observation of an env that just ended is its reset observation (zeros)
-                torch.where(env.ended[:, None, None], self._zero, env.obs, out=out["obs"][t])
-                obs = v._obs = out["obs"][t]
-            else:
-                obs = v.get_obs()                  # zeros right after a reset, like the reference's reset()
-                out["obs"][t] = obs
+            obs = v.get_obs()                  # zeros right after a reset, like the reference's reset()
+            out["obs"][t] = obs
             out["state"][t] = obs.reshape(E, N * D)
             out["episode_start"][t] = self._restart.view(torch.bool)
             if fused:
@@ -289,17 +315,10 @@ class BatchedRunner(object):
                 torch.where(explore, rnd, greedy, out=out["actions"][t])
             elif not fused:
                 out["actions"][t] = greedy
-            if direct:
-                env.step(out["actions"][t])
-                v._obs, v._ended = None, env.ended
-                out["reward"][t] = env.reward_sum
-                out["terminated"][t] = env.ended
-                self._restart = env._ended_u8      # read by the next actor launch, before the next env step rewrites it
-            else:
-                reward, ended, _ = v.step(out["actions"][t])
-                out["reward"][t] = reward
-                out["terminated"][t] = ended
-                self._restart.copy_(ended)
+            reward, ended, _ = v.step(out["actions"][t])
+            out["reward"][t] = reward
+            out["terminated"][t] = ended
+            self._restart.copy_(ended)
         out["obs"][T] = v.get_obs()
         out["state"][T] = v.get_state()
         return out

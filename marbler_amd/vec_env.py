@@ -242,10 +242,24 @@ class VecRobotariumEnv(object):
         self._io.elapsed, self._io.truncated = self.elapsed.data_ptr(), self._trunc_u8.data_ptr()
         self._io.ended, self._io.reward_sum = self._ended_u8.data_ptr(), self.reward_sum.data_ptr()
         self._io.time_limit = self.time_limit
+        # a second argument block for step_into(): the same buffers, three pointers replaced per call, zeros for ended envs
+        self._io_into = _lib.RgStepIO.from_buffer_copy(self._io)
+        self._io_into.zero_obs_on_end = 1
+        self._io_into_ref = C.byref(self._io_into)
 
     def _gymma_views(self, arena):
         E, pad = self.E, self._gymma_pad
         return arena[:4 * E].view(torch.float32), arena[4 * pad:4 * pad + E], arena[5 * pad:5 * pad + E]
+
+    def step_into(self, actions_ptr, obs_ptr, reward_sum_ptr, ended_ptr):
+        """One rg_step whose gymma-shaped outputs go straight into a consumer's buffers (a trainer's time-major batch): the
+        observation [E,N,D] -- with the rows of an env that ends in this step written as ZEROS, the reset observation a gymma
+        user sees next (rg_step_io.zero_obs_on_end) --, the summed reward [E] f32 and the episode-end flags [E] u8.  Device
+        pointers; needs enable_time_limit().  Everything else a step returns (reward per agent, done, dist_travelled,
+        violation, remaining, truncated) lands in the env's own buffers as usual; `self.obs` is NOT written."""
+        io = self._io_into
+        io.obs, io.reward_sum, io.ended = obs_ptr, reward_sum_ptr, ended_ptr
+        return self.lib.rg_step(self._h, actions_ptr, self._io_into_ref, 1 if self.auto_reset else 0, self.seed)
 
     def gymma_outputs_copy(self):
         """(reward_sum [E] f32, ended [E] bool, truncated [E] bool) of the last step as FRESH tensors: one copy launch."""

@@ -143,7 +143,12 @@ if __name__ == "__main__":   # python tests/free_running.py --write : the float6
         # study, not parity: the barrier QP as a restated cvxopt interior-point iterate at reltol = feastol = 1e-2 (what the
         # reference's rps asks of cvxopt; oracle/oracle_core.h barrier_qp_ipm) instead of the exact projection
         ipm = run_oracle(c_oracle, scenario, dict(cfg, qp_solver="cvxopt_restated"), p, E, steps, n_act, np.float64, SEED, ACTION_SEED)
-        out["cases"][name] = {"envs": E, "steps": steps, "float64": f64, "float32": f32, "float64_cvxopt_restated": ipm}
+        # round 5: `barrier_solver: cvxopt` is a mode of the product.  Its float tier (float32 step + ipm_spec_v0 in binary64 = the
+        # HIP kernels of that mode, bit for bit) against the float64 restatement in cvxopt's own operation order: same distributions
+        ipm32 = run_oracle(c_oracle, scenario, dict(cfg, barrier_solver="cvxopt"), p, E, steps, n_act, np.float32, SEED, ACTION_SEED)
+        compare(ipm32, ipm, name + " (barrier_solver: cvxopt, float tier vs float64)")
+        out["cases"][name] = {"envs": E, "steps": steps, "float64": f64, "float32": f32, "float64_cvxopt_restated": ipm,
+                              "float32_cvxopt": ipm32}
         print(name, "collisions, exact projection vs restated cvxopt iterate:", f64["violation_counts"][1], ipm["violation_counts"][1])
         print(name, {k: f64[k] for k in ("episodes", "return_mean", "length_mean", "violation_counts")},
               {k: f32[k] for k in ("episodes", "return_mean", "length_mean", "violation_counts")})

@@ -32,6 +32,7 @@ def test_committed_record_is_self_consistent():
     for name, c in rec["cases"].items():
         assert (c["envs"], c["steps"]) == fr.CASES[name][3:]
         fr.compare(c["float32"], c["float64"], name)
+        fr.compare(c["float32_cvxopt"], c["float64_cvxopt_restated"], name + " (barrier_solver: cvxopt)")
         assert c["float64"]["env_steps"] == c["envs"] * c["steps"]
 
 

@@ -29,3 +29,19 @@ def test_kernels_match_the_float64_oracle_statistically(name, kernel, monkeypatc
     for key in ("episodes", "env_steps", "length_hist", "violation_counts", "remaining_hist"):
         assert got[key] == rec["float32"][key], (name, key)
     assert abs(got["return_mean"] - rec["float32"]["return_mean"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", sorted(fr.CASES))
+def test_interior_point_mode_matches_the_float64_restatement_statistically(name, monkeypatch):
+    """`barrier_solver: cvxopt` at full size: the kernels' statistics equal the float tier's of the record exactly (bit-identical
+    steps) and agree with the float64 restatement of cvxopt's iteration within sampling error -- incl. the collision count, which
+    is where this mode differs from the exact projection (17-21 % fewer, tests/test_free_running_stats.py)."""
+    monkeypatch.setenv("RG_STEP_KERNEL", "group")
+    scenario, ov, n_act, E, steps = fr.CASES[name]
+    rec = json.load(open(RECORD))["cases"][name]
+    got = fr.run_gpu(scenario, dict(ov, barrier_solver="cvxopt"), E, steps, n_act, fr.SEED, fr.ACTION_SEED)
+    fr.compare(got, rec["float64_cvxopt_restated"], f"{name} (barrier_solver: cvxopt) vs the float64 restatement")
+    for key in ("episodes", "env_steps", "length_hist", "violation_counts", "remaining_hist"):
+        assert got[key] == rec["float32_cvxopt"][key], (name, key)
+    assert abs(got["return_mean"] - rec["float32_cvxopt"]["return_mean"]) < 1e-9
+    assert got["violation_counts"][1] < 0.95 * rec["float32"]["violation_counts"][1]      # fewer collisions than the projection

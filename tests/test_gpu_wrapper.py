@@ -140,31 +140,44 @@ def test_batched_runner_collects_transitions():
     assert torch.equal(b2["episode_start"][0], b["terminated"][-1])
 
 
-@pytest.mark.parametrize("epsilon", [0.0, 0.25])
-def test_batched_runner_in_place_path_equals_the_composed_one(epsilon):
-    """BatchedRunner writes a fused GymmaVecEnv's outputs straight into the transition batch (seven launches per time step);
-    over a composed one (fused=False: gym's TimeLimit and the reductions as torch ops around the step) it goes through
-    step() / get_obs().  Same envs, same actor, same exploration stream: the batches must be equal, element for element
-    (a short time limit, so that truncations happen)."""
+@pytest.mark.parametrize("kernel", ["group", "tpe"])
+@pytest.mark.parametrize("key,ov,limit,epsilon", [
+    ("robotarium_gym:PredatorCapturePrey-v0", {}, 25, 0.0),
+    ("robotarium_gym:PredatorCapturePrey-v0", {}, 25, 0.25),
+    ("robotarium_gym:Warehouse-v0", {}, 30, 0.25),                 # rows of 18 floats: not whole 16-byte units
+    ("robotarium_gym:MaterialTransport-v0", {}, 12, 0.25),         # 9-float rows, 20 actions
+    ("robotarium_gym:PredatorCapturePrey-v0", {"predator": 3, "capture": 2, "n_agents": 5}, 25, 0.1)])
+def test_batched_runner_in_place_path_equals_the_composed_one(key, ov, limit, epsilon, kernel, monkeypatch):
+    """BatchedRunner over a fused GymmaVecEnv is TWO launches per time step: the env step writes the next observation (zeros for
+    an env that ended: rg_step_io.zero_obs_on_end), the summed reward and the episode-end flags straight into the transition
+    batch, the actor reads them there.  Over a composed one (fused=False: gym's TimeLimit and the reductions as torch ops around
+    the step) it goes through step() / get_obs().  Same envs, same actor, same exploration stream: the batches must be equal,
+    element for element (a short time limit, so that truncations happen), on both step kernels."""
     import torch
     from marbler_amd.evaluate import BatchedActor
     from marbler_amd.gymma import BatchedRunner, GymmaVecEnv
     from test_gpu_actor import _random_actor
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
     E, T = 96, 70
     batches = []
     for fused in (True, False):
-        v = GymmaVecEnv("robotarium_gym:PredatorCapturePrey-v0", E, time_limit=25, seed=5, fused=fused)
+        v = GymmaVecEnv(key, E, time_limit=limit, seed=5, fused=fused, overrides=ov or None)
         actor = BatchedActor(_random_actor(1, v.obs_size + v.n_agents, 64, v.n_actions, True, seed=4), v.n_agents, device=v.env.device)
         runner = BatchedRunner(v, actor, epsilon=epsilon, seed=9)
         b = runner.run(T)
         b2 = runner.run(7)       # a second call continues the same episodes
-        batches.append((b, b2, int(v.env.done_count.sum())))
+        obs_after = v.get_obs().clone()
+        batches.append((b, b2, int(v.env.done_count.sum()), obs_after))
         v.env.close()
-    (a, a2, na), (c, c2, nc) = batches
-    assert na == nc and int(a["terminated"].sum()) > E
+    (a, a2, na, oa), (c, c2, nc, oc) = batches
+    assert na == nc and int(a["terminated"].sum()) > E // 2
+    assert torch.equal(oa, oc)
     for x, y in ((a, c), (a2, c2)):
-        for key in ("obs", "state", "actions", "reward", "terminated", "episode_start", "avail_actions"):
-            assert torch.equal(x[key], y[key]), key
+        for k in ("obs", "state", "actions", "terminated", "episode_start", "avail_actions"):
+            assert torch.equal(x[k], y[k]), k
+        # the summed reward: the launch adds the agents' rewards in agent order, torch's reduction of the composed path in its own
+        # order -- equal to the last bit for 4 agents, within an ulp of the sum for 5 and more
+        assert torch.allclose(x["reward"], y["reward"], rtol=0, atol=2e-6), "reward"
 
 
 @pytest.mark.parametrize("name", ["pcp_n5", "warehouse_n8", "mt_n6", "viol_PredatorCapturePrey_collision"])

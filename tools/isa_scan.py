@@ -135,9 +135,13 @@ def _is_then_entry(insts, index_of, label_addr, mask):
     it (block placement moved the `then` body out of line) or by falling through the `s_cbranch_execz` behind it?  Then its
     instructions are MEANT to run under that mask, and the `s_or_b64 exec` that follows them is the body's own copy of the join."""
     def saves_mask_before(q):
-        for back in range(q - 1, max(q - 4, -1), -1):
+        # `s_and_saveexec mask, cond` right behind the branch, or the same thing spelt out when the condition had to be fetched
+        # first (round 5, an SGPR-spilled condition): `s_mov_b64 mask, exec ; v_readlane ... ; s_and_b64 sX, mask, sY ; s_mov_b64 exec, sX`
+        for back in range(q - 1, max(q - 8, -1), -1):
             b = insts[back]
             if b.op.startswith(("s_and_saveexec", "s_or_saveexec", "s_andn2_saveexec")) and b.args.split(",")[0].strip() == mask:
+                return True
+            if b.op == "s_mov_b64" and b.args.replace(" ", "") == f"{mask},exec".replace(" ", ""):
                 return True
             if b.op.startswith(BRANCHES):
                 return False
