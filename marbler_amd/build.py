@@ -23,10 +23,16 @@ ARCH = "gfx950"
 # Per-file flags (results are bit-identical either way: the same IEEE operations; tools/ab_job.sh measured them).
 # * thread-per-env kernels: WITHOUT the SLP vectoriser.  Left on, it pairs the x / y halves of the float arithmetic into
 #   v_pk_{add,mul,fma}_f32, which need even-aligned register pairs (more spills at N = 6, a kernel already compiled onto a
-#   register budget) and issue no faster than the two scalar instructions on gfx950: N = 6 272 -> 213 us (-22 %) at 524 288 envs,
-#   MaterialTransport N = 6 473 -> 386, N = 5 158.5 -> 152.1, N = 4 99 -> 94.
+#   register budget): N = 6 272 -> 213 us (-22 %) at 524 288 envs, MaterialTransport N = 6 473 -> 386, N = 5 158.5 -> 152.1, N = 4 99 -> 94.
+#   What a packed instruction is worth by itself was measured in round 5 (tools/ubench/issue.py, profiles/r5_issue_ubench.txt:
+#   independent streams, flop / clk / SIMD): at this kernel's TWO waves per SIMD v_pk_fma_f32 issues 1.43 x the work of two
+#   v_fma_f32 (55.8 against 38.9) but v_pk_mul + v_pk_add only 1.06 x the unfused pair (28.2 against 26.5) -- and the step
+#   is unfused arithmetic for the most part (-ffp-contract=off; fma only where the float spec says so): the 6-43 % on the
+#   instructions that could be paired does not pay for the registers the pairing costs here.  (At ONE wave per SIMD -- the
+#   lane-group kernel's regime -- the same instructions are worth 1.86-2.0 x: hence the opposite flag below.)
 # * lane-group kernels: the opposite, -mllvm -slp-threshold=-60 (pack wherever possible; 1 083 -> 1 227 packed f32 instructions
-#   per translation unit): one wave per SIMD runs a dependent chain and every instruction saved is ~5 cycles -- headline launch
+#   per translation unit): one wave per SIMD issues an instruction every ~5.5 cycles whatever its width (packed / scalar = 2.02
+#   for fma, 1.86 for mul + add in the round-5 microbenchmark), so every pair packed is an issue slot saved -- headline launch
 #   13.16 -> 12.73 us, Warehouse 4096 x 8 12.59 -> 12.40, rg_rollout 8.23 -> 7.97 us per step.
 # Round 3 found that ONE thread-per-env instantiation (MaterialTransport, N = 7) computes wrong poses under
 # -O3 -fno-slp-vectorize.  Round 4 found why (tools/n7_bisect/): ROCm 7.2's register allocator placed
