@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS = 157.3, 2500.0   # dense matrix peaks (MI355X_MICROARCH.md; never the 2:1-sparsity figures)
 
 
-PMC_PROFILE = os.path.join("profiles", "r4_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
-PMC_FALLBACKS = (os.path.join("profiles", "r3_final_pmc_summary.csv"), os.path.join("profiles", "r2_final_pmc_summary.csv"))
+PMC_PROFILE = os.path.join("profiles", "r5_final_pmc_summary.csv")   # newest committed rocprofv3 --pmc passes of this command
+PMC_FALLBACKS = (os.path.join("profiles", "r4_final_pmc_summary.csv"), os.path.join("profiles", "r3_final_pmc_summary.csv"))
 HEADLINE_KERNEL = "rg::step_kernel<0, 8, false, 5, false"   # <PCP, GW 8, step, N 5, single launch[, no gymma block]>
 HEADLINE_GRID = 1024 * 64                                     # 4096 envs at 4 per wavefront: 1024 one-wave workgroups
 # rocprofv3's FETCH_SIZE on gfx950 reports half the bytes read, in every access shape of the step kernels (4 B per lane,
@@ -380,6 +380,39 @@ def saturated_leg(dev, overrides, E=SATURATED_ENVS):
     return out
 
 
+def ipm_leg(dev, overrides, E=ENVS_PER_GPU, K=200):
+    """Side measurement (not `value`): the headline workload with `barrier_solver: cvxopt` -- the certificate's QP evaluated as the
+    reference's stack evaluates it (rps -> cvxopt's interior-point `qp` at reltol = feastol = 1e-2; utilities/controller.py:13-16,23),
+    restated in binary64 (csrc/ipm_qp.h), instead of the exact projection the headline computes.  Same envs, same random policy,
+    one rg_step launch per env step; ~10 interior-point iterations of a 10 x 10 KKT system per QP, two QPs per step."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    env = VecRobotariumEnv("PredatorCapturePrey", E, overrides=dict(overrides, barrier_solver="cvxopt"), device=dev, seed=0, auto_reset=True,
+                           collect_qp_stats=True)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    acts = torch.randint(0, 5, (32, E, env.N), generator=gen, device=dev, dtype=torch.int32)
+    ptrs = [acts[i].data_ptr() for i in range(32)]
+    env.reset()
+    for i in range(40):
+        env.step_raw(ptrs[i % 32])
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(K):
+        env.step_raw(ptrs[i % 32])
+    b.record()
+    torch.cuda.synchronize(dev)
+    ms = a.elapsed_time(b) / K
+    it = env.qp_sweeps.float()
+    out = {"barrier_solver": "cvxopt (RG_QP_CVXOPT: restated interior-point iterate, binary64)", "envs": E, "steps": K,
+           "kernel": "rg::step_kernel<PCP,GW=8,...,QPM=1> + rg::ipm::solve_qp<5,8>", "ms_per_step": ms,
+           "agent_steps_per_s": E * env.N / (ms * 1e-3), "iterations_mean_of_step_max": float(it.mean()), "iterations_max": int(it.max()),
+           "vs_exact_projection": "the headline (`value`) is the same workload with barrier_solver: exact"}
+    env.close()
+    return out
+
+
 def actor_leg(dev, E=4096, N=4, D=16, H=128, A=5, bursts=7, reps=100):
     """Side measurement (not `value`): the fused policy-inference kernel of row f3 (csrc/actor_mfma.hip, rg_actor_forward) at
     the evaluation loop's shape -- PredatorCapturePrey's zoo actor: 4096 envs x 4 agents, 16 observation floats + agent id,
@@ -550,6 +583,9 @@ def main():
                     help="skip the graph_replay side measurement (profiling runs: its launches would mix into the headline kernel's row)")
     ap.add_argument("--counters-child", action="store_true", help=argparse.SUPPRESS)   # a rocprofv3 --pmc pass of live_counters()
     ap.add_argument("--scenario", default="PredatorCapturePrey")
+    ap.add_argument("--barrier-solver", default="exact", choices=("exact", "cvxopt"),
+                    help="how the certificate's QP is evaluated (config key barrier_solver): exact = the projection (the headline); "
+                         "cvxopt = the restated interior-point iterate the reference's stack computes (profiling runs of that mode)")
     ap.add_argument("--spinup-ms", type=float, default=1000.0,
                     help="untimed step launches before reset() + the W warm-up steps, so that a GPU that idled while the host did the CPU "
                          "baseline (or while the previous process exited) is at its clocks when the warm-up starts; 0 = none")
@@ -581,7 +617,7 @@ def main():
     live, live_src = {}, None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu_ref = cpu_baseline()
-        if args.scenario == "PredatorCapturePrey" and args.envs_per_gpu == ENVS_PER_GPU and args.gpus == 1:
+        if args.scenario == "PredatorCapturePrey" and args.envs_per_gpu == ENVS_PER_GPU and args.gpus == 1 and args.barrier_solver == "exact":
             live, live_src = live_counters(args)   # (also before this process touches the GPU)
 
     import torch
@@ -613,6 +649,8 @@ def main():
     K, W = args.steps, args.warmup
 
     overrides = bench_overrides(args.scenario)
+    if args.barrier_solver != "exact":
+        overrides["barrier_solver"] = args.barrier_solver
     # rank 0 reads the YAML; every rank gets the parameter block by RCCL broadcast
     params = make_params(args.scenario, load_config(args.scenario, overrides=overrides)) if rank == 0 else None
     if grouped:
@@ -698,7 +736,7 @@ def main():
         bytes_per_launch = (ALGO_BYTES_PER_ENV_STEP if args.scenario == "PredatorCapturePrey"
                             else ALGO_BYTES_OTHER[args.scenario]) * E
         achieved = bytes_per_launch / (gpu_ms_total / K * 1e-3) / 1e9 if bytes_per_launch else None
-        counters, counters_src = committed_counters() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU) \
+        counters, counters_src = committed_counters() if (args.scenario == "PredatorCapturePrey" and E == ENVS_PER_GPU and args.barrier_solver == "exact") \
             else ({}, None)
         counters_kind = "from_committed_profile"
         if live:
@@ -722,7 +760,8 @@ def main():
             "per_rank_ms_per_step": [round(v[0], 6) for v in per_rank], "per_rank_kernel_ms_per_step": [round(v[1], 6) for v in per_rank],
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scenario}-v0, {E} envs x {N} agents per GPU, random policy, "
-                                   f"auto-reset, update_frequency {env.params.update_frequency}, one rg_step launch per env step; "
+                                   f"auto-reset, update_frequency {env.params.update_frequency}, barrier_solver {args.barrier_solver}, "
+                                   f"one rg_step launch per env step; "
                                    f"{args.spinup_ms:g} ms of untimed spin-up launches + reset() before the {W} warm-up steps",
                        "envs_per_gpu": E, "agents": N, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -751,12 +790,13 @@ def main():
             out["episodes"] = {"finished": n_ep,
                                "mean_return": float(rs.sum().item() / max(n_ep, 1)),
                                "mean_length": float(ss.sum().item() / max(n_ep, 1))}
-        if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey":
+        if world == 1 and not args.no_saturated and args.scenario == "PredatorCapturePrey" and args.barrier_solver == "exact":
             if not args.no_graph:
                 out["graph_replay"] = graph_leg(env, dev, ptrs, min(K, 100))
             out["rollout"] = rollout_leg(env, dev, n_act, 777)
             out["saturated"] = saturated_leg(dev, overrides)
             out["actor"] = actor_leg(dev)
+            out["interior_point_mode"] = ipm_leg(dev, overrides)
             out["saturated_2m"] = saturated_leg(dev, overrides, 4 * SATURATED_ENVS)
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref

@@ -1393,6 +1393,9 @@ void FN(orc_atan2)(int n, const REAL *y, const REAL *x, REAL *o) {
 #if ORC_IS_F32
 /* tests: ipm_spec_v0 on binary32 records (xi_x, xi_y, uhat_x, uhat_y) x N, exactly what the kernels' LDS records hold; the iterate
  * replaces uhat.  Returns the iteration count. */
+void orc_ipm_rcp(int n, const double *v, double *r) {
+    for (int i = 0; i < n; ++i) r[i] = ipm_rcp(v[i]);
+}
 int orc_ipm_spec_f32io(const orc_params *p, int N, float *io) {
     double xi[ORC_MAXN], yi[ORC_MAXN], ux[ORC_MAXN], uy[ORC_MAXN];
     for (int a = 0; a < N; ++a) {
