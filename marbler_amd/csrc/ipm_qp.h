@@ -28,7 +28,8 @@
 
 #include <type_traits>
 
-#include "../../include/robogym.h"
+#include "device_common.h"
+#include "probes/diag.h"
 
 namespace rg {
 namespace ipm {
@@ -124,6 +125,7 @@ struct LdsRows {
     __device__ __forceinline__ f64x2 e(int c) const { return *reinterpret_cast<const lds_f64x2 *>(ws + L::E + 2 * c); }
     __device__ __forceinline__ void set_e(int c, f64x2 v) { *reinterpret_cast<lds_f64x2 *>(ws + L::E + 2 * c) = v; }
     __device__ __forceinline__ f64x2 sz(int c) const { return *reinterpret_cast<const lds_f64x2 *>(ws + L::SZ + 2 * c); }
+    __device__ __forceinline__ double s(int c) const { return ws[L::SZ + 2 * c]; }
     __device__ __forceinline__ void set_sz(int c, f64x2 v) { *reinterpret_cast<lds_f64x2 *>(ws + L::SZ + 2 * c) = v; }
     __device__ __forceinline__ f64x2 rr(int c) const { return *reinterpret_cast<const lds_f64x2 *>(ws + L::RR + 2 * c); }
     __device__ __forceinline__ double rz(int c) const { return ws[L::RR + 2 * c]; }
@@ -151,6 +153,7 @@ struct RegRows {
     __device__ __forceinline__ f64x2 e(int c) const { return e_[c]; }
     __device__ __forceinline__ void set_e(int c, f64x2 v) { e_[c] = v; }
     __device__ __forceinline__ f64x2 sz(int c) const { return sz_[c]; }
+    __device__ __forceinline__ double s(int c) const { return sz_[c].x; }
     __device__ __forceinline__ void set_sz(int c, f64x2 v) { sz_[c] = v; }
     __device__ __forceinline__ f64x2 rr(int c) const { return rr_[c]; }
     __device__ __forceinline__ double rz(int c) const { return rr_[c].x; }
@@ -247,6 +250,27 @@ __device__ __forceinline__ void solve(const double (&K)[N * (2 * N + 1)], const 
 }
 
 __device__ __forceinline__ void phase_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// The step to the boundary t = max(0, -ds/s, -dz/z) as a fraction n / d (d > 0), compared by cross-multiplication.  Order of the
+// comparisons (oracle_core.h): LANES interleaved runs of rows, each folded in row order from 0 / 1, then a balanced tree in which
+// the lower run is kept unless the higher one is strictly larger.
+struct Frac {
+    double n, d;
+};
+__device__ __forceinline__ Frac frac_fold(Frac a, double n, double d) { return (n * a.d > a.n * d) ? Frac{n, d} : a; }
+__device__ __forceinline__ Frac frac_meet(Frac lo, Frac hi) { return (hi.n * lo.d > lo.n * hi.d) ? hi : lo; }
+template <int K>
+__device__ __forceinline__ double xor_lane_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = static_cast<unsigned>(xor_lane_i<K>(static_cast<int>(b))), hi = static_cast<unsigned>(xor_lane_i<K>(static_cast<int>(b >> 32)));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+// the tree over the 8 lanes of a group (every lane ends with the same fraction): stage w pairs lane l with l ^ w
+template <int W>
+__device__ __forceinline__ Frac frac_meet_lanes(Frac mine, int sub) {
+    const Frac other = {xor_lane_f64<W>(mine.n), xor_lane_f64<W>(mine.d)};
+    return (sub & W) ? frac_meet(other, mine) : frac_meet(mine, other);
+}
 
 // the rows of lane `sub`: f(row c, i, j) for c = sub, sub + GS, ... < m.  Every lane of the wavefront executes the same
 // instructions; the row (and its robots) differ per lane, so per-robot data is fetched from LDS by address.  The slot loop is
@@ -348,7 +372,6 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
         R.set_sz(c, f64x2{-z, z});
     });
     phase_fence();
-    double gap;
     {
         double ns = 0.0, tz = -1e300, ts = -1e300;
 #pragma unroll
@@ -362,13 +385,11 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
         const double lim2 = 1e-16 * (ns > 1.0 ? ns : 1.0);
         const bool shift_s = ts >= 0.0 || ts * ts <= lim2, shift_z = tz >= 0.0 || tz * tz <= lim2;
         const double as = 1.0 + ts, az = 1.0 + tz;
-        gap = 0.0;
 #pragma unroll
         for (int c = 0; c < m; ++c) {   // (replicated: every lane of the group writes the same values)
             f64x2 sz = R.sz(c);
             sz.x = shift_s ? sz.x + as : sz.x;
             sz.y = shift_z ? sz.y + az : sz.y;
-            gap = __builtin_fma(sz.x, sz.y, gap);
             R.set_sz(c, sz);
         }
     }
@@ -395,10 +416,12 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
     phase_fence();
     row_phase(false, 0.0);
     int iters = 0;
+    RG_IPM_T0()
     for (;; ++iters) {
         phase_fence();
-        // residuals rx = q + 2x + G'z, costs and the sums of the stopping rule   [replicated, row order]
-        double f0 = 0.0, nrx = 0.0, nrz = 0.0, zrz = 0.0;
+        RG_IPM_TICK(0)
+        // residuals rx = q + 2x + G'z, costs, the gap s.z and the sums of the stopping rule   [replicated, row order]
+        double f0 = 0.0, nrx = 0.0, nrz = 0.0, zrz = 0.0, gap = 0.0;
 #pragma unroll
         for (int kk = 0; kk < n; ++kk) {
             rx[kk] = __builtin_fma(2.0, x[kk], q[kk]);
@@ -419,6 +442,7 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
                     rx[2 * j + 1] = __builtin_fma(t, e.y, rx[2 * j + 1]);
                     nrz = __builtin_fma(rz, rz, nrz);
                     zrz = __builtin_fma(0.5 * t, rz, zrz);   // z = t / 2 exactly
+                    gap = __builtin_fma(R.s(c), 0.5 * t, gap);
                 }
         }
 #pragma unroll
@@ -426,8 +450,11 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
         const double pcost = f0, dcost = (f0 + zrz) - gap;
         const bool rel_ok = pcost < 0.0 ? gap <= k.reltol * -pcost : dcost > 0.0 ? gap <= k.reltol * dcost : false;
         if ((nrz <= resz0sq && nrx <= resx0sq && (gap <= k.abstol || rel_ok)) || iters == k.maxiters) break;
+        RG_IPM_TICK(1)
         assemble<N>(R, K, false);
+        RG_IPM_TICK(2)
         ldl<N>(K, rd);
+        RG_IPM_TICK(3)
         const double mu = gap * (1.0 / static_cast<double>(m));
         double sigmamu = 0.0, step = 1.0;
 #pragma unroll
@@ -459,7 +486,10 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
 #pragma unroll
             for (int a = 0; a < N; ++a) R.set_dx(a, f64x2{dx[2 * a], dx[2 * a + 1]});
             phase_fence();
-            // ds = -rz - G dx;  dz = (rc - z ds) / s;  the predictor also leaves dsa dza for the corrector   [distributed]
+            RG_IPM_TICK(4)
+            // ds = -rz - G dx;  dz = (rc - z ds) / s;  the predictor also leaves dsa dza for the corrector   [distributed]; each lane
+            // folds its own rows' candidates for the step to the boundary as it goes
+            Frac best = {0.0, 1.0};
             my_rows<N, GS>(sub, [&](int c, int i, int j) {
                 const f64x2 e = R.e(c), sz = R.sz(c);
                 const f64x2 rr = R.rr(c);
@@ -470,22 +500,46 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
                 const double dz = __builtin_fma(-sz.y, ds, rc) * rr.y;
                 R.set_dd(c, f64x2{ds, dz});
                 if (pass == 0) R.set_a(c, ds * dz);
+                if constexpr (GS == 8) {
+                    best = frac_fold(best, -ds, sz.x);
+                    best = frac_fold(best, -dz, sz.y);
+                }
             });
             phase_fence();
-            // sum ds dz and the step to the boundary t = max(0, -ds/s, -dz/z) as a fraction tn / td   [replicated, row order]
-            double dsdz = 0.0, tn = 0.0, td = 1.0;
+            RG_IPM_TICK(5)
+            // sum ds dz [replicated, row order] and the step to the boundary as a fraction tn / td
+            double dsdz = 0.0, tn, td;
 #pragma unroll
             for (int c = 0; c < m; ++c) {
-                const f64x2 d = R.dd(c), sz = R.sz(c);
+                const f64x2 d = R.dd(c);
                 dsdz = __builtin_fma(d.x, d.y, dsdz);
-                if (-d.x * td > tn * sz.x) {
-                    tn = -d.x;
-                    td = sz.x;
+            }
+            if constexpr (GS == 8) {   // N >= 5: the spec's 8 interleaved runs are the group's lanes; they meet by lane permutes
+                static_assert(N >= 5, "groups of 8 carry five to eight robots");
+                best = frac_meet_lanes<1>(best, sub);
+                best = frac_meet_lanes<2>(best, sub);
+                best = frac_meet_lanes<4>(best, sub);
+                tn = best.n;
+                td = best.d;
+            } else {                   // every row in this lane
+                constexpr int LANES = N <= 4 ? 1 : 8;
+                Frac p[LANES];
+#pragma unroll
+                for (int l = 0; l < LANES; ++l) {
+                    p[l] = Frac{0.0, 1.0};
+#pragma unroll
+                    for (int c = l; c < m; c += LANES) {
+                        const f64x2 d = R.dd(c), sz = R.sz(c);
+                        p[l] = frac_fold(p[l], -d.x, sz.x);
+                        p[l] = frac_fold(p[l], -d.y, sz.y);
+                    }
                 }
-                if (-d.y * td > tn * sz.y) {
-                    tn = -d.y;
-                    td = sz.y;
-                }
+#pragma unroll
+                for (int w = 1; w < LANES; w *= 2)
+#pragma unroll
+                    for (int l = 0; l < LANES; l += 2 * w) p[l] = frac_meet(p[l], p[l + w]);
+                tn = p[0].n;
+                td = p[0].d;
             }
             if (pass == 0) {
                 step = tn > td ? td * rcp_spec(tn) : 1.0;
@@ -495,6 +549,7 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
             } else {
                 step = 0.99 * td < tn ? (0.99 * td) * rcp_spec(tn) : 1.0;
             }
+            RG_IPM_TICK(6)
         }
 #pragma unroll
         for (int kk = 0; kk < n; ++kk) x[kk] = __builtin_fma(step, dx[kk], x[kk]);
@@ -502,13 +557,7 @@ __device__ __attribute__((noinline)) int solve_qp(const Consts k, float4 *io_gen
         for (int a = 0; a < N; ++a) R.set_x(a, f64x2{x[2 * a], x[2 * a + 1]});
         phase_fence();
         row_phase(true, step);   // s, z updated; the next iteration's row data
-        phase_fence();
-        gap = 0.0;
-#pragma unroll
-        for (int c = 0; c < m; ++c) {
-            const f64x2 sz = R.sz(c);
-            gap = __builtin_fma(sz.x, sz.y, gap);
-        }
+        RG_IPM_TICK(7)
     }
     phase_fence();
 #pragma unroll

@@ -216,3 +216,20 @@ constexpr bool kTpeGuard = false;
 #else
 #define RG_GUARDED(dst, lo, hi, code, stmt) stmt
 #endif
+
+// ---- interior-point iteration (csrc/ipm_qp.h): -DRG_IPM_STAMPS accumulates the wave's ticks per phase of an iteration in
+// `ipm_ticks[8]` (a __device__ array the diagnostic driver reads): 0 row phase, 1 residuals + stopping rule, 2 assembly,
+// 3 factorisation, 4 right-hand side + solve (both passes), 5 ds / dz rows (both), 6 step to the boundary (both), 7 update
+#ifdef RG_IPM_STAMPS
+namespace rg { namespace ipm { __device__ unsigned long long ipm_ticks[8]; } }
+#define RG_IPM_T0() unsigned long long ipm_t_ = __builtin_amdgcn_s_memtime();
+#define RG_IPM_TICK(i)                                                                              \
+    {                                                                                               \
+        const unsigned long long t2_ = __builtin_amdgcn_s_memtime();                                \
+        if (threadIdx.x == 0 && blockIdx.x == 0) rg::ipm::ipm_ticks[i] += t2_ - ipm_t_;             \
+        ipm_t_ = t2_;                                                                               \
+    }
+#else
+#define RG_IPM_T0()
+#define RG_IPM_TICK(i)
+#endif

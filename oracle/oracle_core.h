@@ -501,7 +501,8 @@ static int FN(barrier_qp_ipm)(const orc_params *p, int N, const REAL *xix, const
  *     off-diagonal block is -w e e' of its one pair) and factored K = L D L' without square roots; every solve is forward, scale,
  *     backward with fma chains in ascending index order;
  *   - ONE reciprocal per row per iteration (1 / s_c) and one per pivot; the step to the boundary max(-ds/s, -dz/z) is found by
- *     cross-multiplied comparisons (a/b > c/d  <=>  a d > c b, all denominators positive) and divided once;
+ *     cross-multiplied comparisons (a/b > c/d  <=>  a d > c b, all denominators positive) in a fixed order (interleaved runs of
+ *     rows + a balanced tree, see below) and divided once;
  *   - no division instruction: every reciprocal is ipm_rcp below (exponent-field seed + five Newton steps: deterministic, within
  *     two ulp; arguments are positive by construction -- s_c, z_c stay inside the cone, the pivots of 2I + PSD are >= 2);
  *   - no square root anywhere: the residual tests compare squared norms (|r| <= tol max(1, |r0|)  <=>  r.r <= tol^2 max(1, r0.r0));
@@ -725,8 +726,12 @@ static int barrier_qp_ipm_spec(const ipm_consts *kc, int N, const double *xix, c
                     }
             }
             ipm_solve(n, K, rd, dx);
-            /* ds = -rz - G dx;  dz = (rc - z o ds) / s;  step to the boundary t = max(0, -ds/s, -dz/z) as a fraction tn / td */
-            double dsdz = 0.0, tn = 0.0, td = 1.0;
+            /* ds = -rz - G dx;  dz = (rc - z o ds) / s;  step to the boundary t = max(0, -ds/s, -dz/z) as a fraction tn / td.
+             * The maximum is taken over LANES interleaved runs of rows (run l: rows l, l + LANES, ...; each run folds its rows'
+             * two candidates in order, starting from 0 / 1) whose results meet in a balanced tree (0 with 1, 2 with 3, ...; the
+             * lower run is kept unless the higher one is strictly larger): LANES = 1 up to four robots, 8 from five on -- the
+             * kernel's lane groups fold their own rows and meet by lane permutes, a chain of 2 + 3 comparisons instead of 2m. */
+            double dsdz = 0.0, tn, td;
             {
                 int c = 0;
                 for (int i = 0; i < N - 1; ++i)
@@ -736,9 +741,22 @@ static int barrier_qp_ipm_spec(const ipm_consts *kc, int N, const double *xix, c
                         ds[c] = -rz[c] - gdx;
                         dz[c] = __builtin_fma(-z[c], ds[c], rc) * rs[c];
                         dsdz = __builtin_fma(ds[c], dz[c], dsdz);
-                        if (-ds[c] * td > tn * s[c]) { tn = -ds[c]; td = s[c]; }
-                        if (-dz[c] * td > tn * z[c]) { tn = -dz[c]; td = z[c]; }
                     }
+                const int LANES = N <= 4 ? 1 : 8;
+                double pn[8], pd[8];
+                for (int l = 0; l < LANES; ++l) {
+                    pn[l] = 0.0;
+                    pd[l] = 1.0;
+                    for (c = l; c < m; c += LANES) {
+                        if (-ds[c] * pd[l] > pn[l] * s[c]) { pn[l] = -ds[c]; pd[l] = s[c]; }
+                        if (-dz[c] * pd[l] > pn[l] * z[c]) { pn[l] = -dz[c]; pd[l] = z[c]; }
+                    }
+                }
+                for (int w = 1; w < LANES; w *= 2)
+                    for (int l = 0; l < LANES; l += 2 * w)
+                        if (pn[l + w] * pd[l] > pn[l] * pd[l + w]) { pn[l] = pn[l + w]; pd[l] = pd[l + w]; }
+                tn = pn[0];
+                td = pd[0];
             }
             if (pass == 0) {
                 step = tn > td ? td * ipm_rcp(tn) : 1.0;         /* min(1, 1 / t);  t == 0 -> 1 */

@@ -75,6 +75,12 @@ if __name__ == "__main__":
             got, got_it, ticks = d_io.cpu().numpy(), d_it.cpu().numpy(), d_t.cpu().numpy()
             same = bool(np.array_equal(got[:, :N].view(np.uint32), want[:, :N].view(np.uint32)) and np.array_equal(got_it, want_it))
             wave_max_it = np.array([want_it[w * per_wave:(w + 1) * per_wave].max() for w in range(waves)])
+            if hasattr(lib, "ipm_read_ticks"):     # -DRG_IPM_STAMPS build: wave 0's ticks per phase, summed over its QP
+                tk = (C.c_ulonglong * 8)()
+                lib.ipm_read_ticks(tk, 1)
+                its = int(want_it[:per_wave].max())
+                print("  phases (ticks per iteration of wave 0: rows, residuals, assembly, factorisation, rhs+solve x2, ds/dz x2, step x2, update):",
+                      [int(v / max(its, 1) / 2) for v in tk], "iterations", its)
             print(json.dumps({"N": N, "per_lane": per_lane, "instances": args.inst, "bit_exact_vs_cpu_twin": same,
                               "iterations_mean": round(float(want_it.mean()), 2), "iterations_max": int(want_it.max()),
                               "ticks_per_qp_wave_mean": int(ticks.mean()), "ticks_per_wave_iteration": int((ticks / (wave_max_it + 1.0)).mean())}), flush=True)

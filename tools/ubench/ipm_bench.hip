@@ -39,3 +39,12 @@ extern "C" int ipm_run(const rg_scenario_params *p, float4 *io, int *iters, long
     ipm_kernel<<<(n_inst + per_wave - 1) / per_wave, 64>>>(*p, io, iters, ticks, N, n_inst, per_lane);
     return static_cast<int>(hipDeviceSynchronize());
 }
+
+#ifdef RG_IPM_STAMPS
+extern "C" int ipm_read_ticks(unsigned long long *out, int reset) {
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rg::ipm::ipm_ticks), sizeof(zero)) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(rg::ipm::ipm_ticks), zero, sizeof(zero)) != hipSuccess) return 2;
+    return 0;
+}
+#endif
