@@ -40,6 +40,12 @@ struct rg_handle {
 // 92 % VALU issue there -- stays ahead at every batch size.  RG_STEP_KERNEL=group|tpe forces one (tests, profiling).
 static int32_t tpe_min_envs(const rg_scenario_params &p) {
     const bool mt = p.scenario == RG_SCN_MATERIAL_TRANSPORT, pcp = p.scenario == RG_SCN_PREDATOR_CAPTURE_PREY;
+    // RG_QP_CVXOPT: the launch is the interior-point iteration, one wave per SIMD in either kernel.  A lane group carries one env
+    // through it in ~0.7 x the time a single lane needs, a wavefront of lanes carries eight times as many: the lane-group kernel
+    // while its waves fit the chip at once (8 192 envs), the other one from the second generation on.  Measured ladder, round 5
+    // (tools/ipm_probe.py --cross, profiles/r5_ipm_crossover.jsonl): N = 5  8 192 envs 166 vs 211 us, 16 384 290 vs 215;
+    // N = 4  16 384 95 vs 95, 24 576 157 vs 99; at 65 536 x 5 981 vs 260 us.
+    if (p.qp_mode == RG_QP_CVXOPT) return p.n_agents == 5 ? 12288 : 20480;
     switch (p.n_agents) {
         case 2: return 65536;
         case 3: return pcp ? 98304 : 65536;

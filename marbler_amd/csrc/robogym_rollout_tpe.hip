@@ -1,5 +1,6 @@
 // robogym_rollout_tpe.hip -- instantiates the thread-per-env kernels (step_tpe.h) for rg_rollout.
 #include "step_tpe.h"
+#include "step_tpe_ipm.h"
 
 namespace rg {
 

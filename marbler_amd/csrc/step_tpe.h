@@ -76,11 +76,19 @@ __device__ __forceinline__ void block_sums(const float (&pa)[N], const float (&p
         }
     }
 }
-// ------------------------------------------------------------------ controller (a3..a8)
+// RG_QP_CVXOPT in this kernel: the lane's env, its N records (xi, thresholded uhat) in the lane's slice of the wave's LDS block,
+// through the interior-point iteration of ipm_qp.h (rows in registers: one lane computes every row).  Defined in step_tpe_ipm.h,
+// which the instantiation units include -- the host simulation of tests/sanitize/ never instantiates this mode.
 template <int N>
+__device__ int ipm_lane(const rg_scenario_params &p, const float (&xix)[N], const float (&xiy)[N], float (&ux)[N], float (&uy)[N],
+                        float *rec);
+
+// ------------------------------------------------------------------ controller (a3..a8)
+// QPM: include/robogym.h RG_QP_*; rec: the lane's LDS slice for the records of the interior-point mode
+template <int N, int QPM = 0>
 __device__ __forceinline__ int controller(const rg_scenario_params &p, const Consts &k, const float (&x)[N],
                                           const float (&y)[N], const float (&c)[N], const float (&s)[N],
-                                          const float (&gx)[N], const float (&gy)[N], float (&v)[N], float (&w)[N]) {
+                                          const float (&gx)[N], const float (&gy)[N], float (&v)[N], float (&w)[N], float *rec = nullptr) {
     float xix[N], xiy[N], ux[N], uy[N], uhx[N], uhy[N];
 #pragma unroll
     for (int a = 0; a < N; ++a) {  // a4 uni_to_si_states, a5 si_position_controller
@@ -92,6 +100,33 @@ __device__ __forceinline__ int controller(const rg_scenario_params &p, const Con
         const bool clip = nrm > k.pvl;
         ux[a] = clip ? dx * sc : dx;
         uy[a] = clip ? dy * sc : dy;
+    }
+    if constexpr (QPM == RG_QP_CVXOPT) {
+        // a6 as the reference's stack evaluates it (oracle/oracle_core.h barrier_qp_ipm_spec): threshold, interior-point iterate
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const float n2u = ux[a] * ux[a] + uy[a] * uy[a];
+            if (n2u > k.bml * k.bml) {
+                const float sc = k.bml / __builtin_sqrtf(n2u);
+                ux[a] = ux[a] * sc;
+                uy[a] = uy[a] * sc;
+            }
+        }
+        const int iters = ipm_lane<N>(p, xix, xiy, ux, uy, rec);
+#pragma unroll
+        for (int a = 0; a < N; ++a) {  // a7 si_to_uni_dyn, a8 set_velocities
+            float vv = c[a] * ux[a] + s[a] * uy[a];
+            float ww = k.inv_pd * (-s[a] * ux[a] + c[a] * uy[a]);
+            ww = ww > k.wlim ? k.wlim : ww;
+            ww = ww < -k.wlim ? -k.wlim : ww;
+            vv = vv > k.vmax ? k.vmax : vv;
+            vv = vv < -k.vmax ? -k.vmax : vv;
+            ww = ww > k.wmax ? k.wmax : ww;
+            ww = ww < -k.wmax ? -k.wmax : ww;
+            v[a] = vv;
+            w[a] = ww;
+        }
+        return iters;
     }
     // a6 barrier certificate (oracle/oracle_core.h barrier_qp): pair constants
     const float bgain = p.barrier_gain, ugain = p.unsafe_barrier_gain, qp_rtol = p.qp_rtol;
@@ -412,7 +447,7 @@ __device__ __forceinline__ void write_obs_staged(const float (&x)[N], const floa
 
 // ------------------------------------------------------------------ one env step on one lane
 // returns whether the episode ended (roboEnv.py:38-96 + the scenario's step())
-template <int SCN, int N>
+template <int SCN, int N, int QPM = 0>
 __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv, const int e, int &rc_raw, const Stage &sg) {
     RG_STAMPS_BEGIN()
     const rg_scenario_params &p = a.p;
@@ -494,7 +529,8 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
         const int n = (U - it0) < period ? (U - it0) : period;
 #pragma unroll
         for (int i = 0; i < N; ++i) sincos_spec(th[i], s[i], c[i]);
-        const int sw = controller<N>(p, k, x, y, c, s, gx, gy, v, w);
+        // (interior-point mode: the records go through the lane's slice of the staging block, which is idle until the stores)
+        const int sw = controller<N, QPM>(p, k, x, y, c, s, gx, gy, v, w, QPM ? sg.buf + sg.lane * (4 * N) : nullptr);
         max_sweeps = sw > max_sweeps ? sw : max_sweeps;
         RG_PIN_ARR2(N, v, w);
         if (it0 == 0) RG_TSTAMP_MAIN(1);  // first controller
@@ -1033,14 +1069,16 @@ __device__ __forceinline__ bool step_env(const KernelArgs &a, const StepView &sv
 }
 
 // ------------------------------------------------------------------ the step kernel
-template <int SCN, int N, bool ROLLOUT>
+// QPM = RG_QP_CVXOPT: the interior-point mode's own instantiations, compiled for one wave per SIMD (the iteration of ipm_qp.h
+// wants the whole register file; the launch is then ~90 % that iteration).
+template <int SCN, int N, bool ROLLOUT, int QPM = 0>
 // Waves per SIMD (tpe_waves above; these files are compiled without the SLP vectoriser, build.py FILE_FLAGS, which alone
 // took N = 5 from 244 to 203 VGPRs, N <= 4 from 168 + 7 spilled to 147 and N = 6 from 76 to 19 spilled values): N <= 4
 // three, N = 5 two -- both now the compiler's own allocation --, N = 6 two on a forced 256-register budget (19 values in
 // scratch; one wave per SIMD measured 34 % slower in round 2), N >= 7 one.  Measured and rejected in round 3 at 524 288 envs
 // (tools/tpe_ab_probe.py, -DRG_TPE_W5=3 / -DRG_TPE_W4=4 / -DRG_TPE_W78=2): N = 5 at three waves (32 spilled) 169.6 vs
 // 153.1 us, N = 4 at four (18 spilled) 108.7 vs 99.5, N = 7 at two (93 spilled) 390.6 vs 348.0, N = 8 at two 1448 vs 481.
-RG_TPE_WAVES_ATTR(tpe_waves(N) ? tpe_waves(N) : 1)
+RG_TPE_WAVES_ATTR(QPM ? 1 : tpe_waves(N) ? tpe_waves(N) : 1)
 __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     __shared__ union alignas(16) {
         Lds<WAVE> reset;        // fused reset (after the step, behind a barrier)
@@ -1061,7 +1099,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
     for (int t = 0; t < num_steps; ++t) {
         if (t) __syncthreads();  // the previous step's stores and resets are visible to the wave
         int rc_raw = -1;
-        const bool done = step_env<SCN, N>(a, step_view(a, t, N, a.p.obs_dim), e, rc_raw, sg);
+        const bool done = step_env<SCN, N, QPM>(a, step_view(a, t, N, a.p.obs_dim), e, rc_raw, sg);
         // fused auto-reset (scenario.reset(); ~1 env in 70 per step): the whole wave resets each finished
         // env together, as one 64-lane group of the shared sampler
         if (a.auto_reset) {
@@ -1079,6 +1117,22 @@ __global__ __launch_bounds__(WAVE) void step_kernel(const KernelArgs a) {
 template <int SCN, bool ROLLOUT>
 static hipError_t launch_scn(const KernelArgs &a, hipStream_t stream) {
     const int grid = (a.E + WAVE - 1) / WAVE;
+    if (a.p.qp_mode == RG_QP_CVXOPT) {   // N <= 5: the iteration's rows and KKT matrix in one lane's registers (tpe_supported)
+        switch (a.p.n_agents) {
+#define RG_CASE(NN)                                                                                                      \
+    case NN:                                                                                                             \
+        hipLaunchKernelGGL((step_kernel<SCN, NN, ROLLOUT, RG_QP_CVXOPT>), dim3(grid), dim3(WAVE), 0, stream, a);         \
+        break;
+            RG_CASE(2)
+            RG_CASE(3)
+            RG_CASE(4)
+            RG_CASE(5)
+#undef RG_CASE
+            default:
+                return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (a.p.n_agents) {
 #define RG_CASE(NN)                                                                                   \
     case NN:                                                                                          \
@@ -1114,7 +1168,10 @@ static hipError_t launch_tpe(const KernelArgs &a, hipStream_t stream) {
             return tpe::launch_scn<RG_SCN_SIMPLE, ROLLOUT>(a, stream);
         case RG_SCN_ARCTIC_TRANSPORT: {
             const int grid = (a.E + WAVE - 1) / WAVE;
-            hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
+            if (a.p.qp_mode == RG_QP_CVXOPT)
+                hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, ROLLOUT, RG_QP_CVXOPT>), dim3(grid), dim3(WAVE), 0, stream, a);
+            else
+                hipLaunchKernelGGL((tpe::step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, ROLLOUT>), dim3(grid), dim3(WAVE), 0, stream, a);
             return hipGetLastError();
         }
         default:

@@ -31,17 +31,43 @@ CASES = [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5
          ("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5, "cvxopt_maxiters": 3}, 5, 80, 64)]   # the iteration cap binds
 
 
+@pytest.mark.parametrize("kernel", ["group", "tpe"])
 @pytest.mark.parametrize("scenario,ov,n_act,steps,E", CASES)
-def test_interior_point_mode_rollout_is_bit_exact(scenario, ov, n_act, steps, E, oracle_lib, monkeypatch):
-    monkeypatch.setenv("RG_STEP_KERNEL", "group")
+def test_interior_point_mode_rollout_is_bit_exact(scenario, ov, n_act, steps, E, kernel, oracle_lib, monkeypatch):
+    """Both step kernels: a lane group per env (rows in LDS, row phases spread over the group's lanes; every agent count up to 8)
+    and one lane per env (everything in the lane's registers; up to 5 agents -- the library falls back to the lane-group kernel
+    above that, so those cases run it twice)."""
+    import torch
+    from marbler_amd import VecRobotariumEnv
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
+    probe = VecRobotariumEnv(scenario, 4, overrides=dict(ov, **IPM))
+    n, which = probe.N, probe.step_kernel
+    probe.close()
+    assert which == (kernel if (kernel == "group" or 2 <= n <= 5) else "group"), (n, which)
     _rollout_bit_exact(scenario, dict(ov, **IPM), n_act, steps, oracle_lib, E, require_done=False)
 
 
 @pytest.mark.parametrize("scenario,ov,n_act,E", [("PredatorCapturePrey", {"predator": 3, "capture": 2, "n_agents": 5}, 5, 130),
                                                   ("Warehouse", {"n_agents": 8}, 5, 65),
                                                   ("MaterialTransport", {}, 20, 64), ("ArcticTransport", {}, 5, 33)])
-def test_interior_point_mode_multi_step_launch_equals_single_steps(scenario, ov, n_act, E):
+@pytest.mark.parametrize("kernel", ["group", "tpe"])
+def test_interior_point_mode_multi_step_launch_equals_single_steps(scenario, ov, n_act, E, kernel, monkeypatch):
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
     _rollout_equals_steps(scenario, dict(ov, **IPM), n_act, E, K=10, reps=3, require_done=False)
+
+
+def test_interior_point_mode_picks_the_kernel_by_batch_size():
+    """The library's own choice (no RG_STEP_KERNEL): a lane group per env up to the cross-over, one lane per env beyond, and the
+    two agree bit for bit (a short free-running comparison at a batch on either side is in the parametrised cases above)."""
+    from marbler_amd import VecRobotariumEnv
+    ov = dict({"predator": 3, "capture": 2, "n_agents": 5}, **IPM)
+    for E, want in ((4096, "group"), (8192, "group"), (16384, "tpe"), (65536, "tpe")):
+        env = VecRobotariumEnv("PredatorCapturePrey", E, overrides=ov)
+        assert env.step_kernel == want, (E, env.step_kernel)
+        env.close()
+    env = VecRobotariumEnv("Warehouse", 65536, overrides=dict({"n_agents": 8}, **IPM))
+    assert env.step_kernel == "group"          # N > 5: the lane-group kernel at every batch size
+    env.close()
 
 
 def test_interior_point_mode_is_refused_above_eight_agents():

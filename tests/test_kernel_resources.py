@@ -133,6 +133,10 @@ def test_shipped_resources_thread_per_env(shipped):
     """Occupancy / scratch / LDS of the shipped thread-per-env kernels, from the code objects' own metadata.  The kernel
     lives at the edge of the register file: one more value live through the step and N = 5 drops from two waves per SIMD
     to one (measured: 166 -> 239 us per step at 524 288 envs) without any test failing."""
+    def _res(sh, fragment):     # (the exact-projection instantiations: last template argument 0; the interior-point ones are checked below)
+        hits = {k: r["resources"] for k, r in sh.items() if fragment in k and k.endswith("ELi0EEEvNS_10KernelArgsE")}
+        assert hits, fragment
+        return hits
     for scn in range(4):
         for k, r in _res(shipped, f"3tpe11step_kernelILi{scn}ELi5ELb0E").items():      # N = 5: two waves per SIMD, no spill
             assert r["occupancy"] >= 2 and r["scratch"] == 0 and r["spill"] == 0 and r["lds"] <= 20 * 1024, (k, r)
@@ -165,6 +169,10 @@ def test_shipped_interior_point_kernels(shipped):
         assert r["occupancy"] == 1 and r["vgpr"] > 256 and r["lds"] <= 40 * 1024, (k, r)   # (accumulation registers in use: one wave per SIMD)
     bodies = [k for k in shipped if "3ipm8solve_qpI" in k]
     assert len(bodies) >= 7, bodies
+    tpe = {k: r["resources"] for k, r in shipped.items() if "3tpe11step_kernelI" in k and k.endswith("ELi1EEEvNS_10KernelArgsE")}
+    assert len(tpe) >= 2 * 13            # N = 2 .. 5 (three scenarios), 4 .. 5 (MaterialTransport), ArcticTransport: single- and multi-step
+    for k, r in tpe.items():             # (small agent counts leave registers over; N = 5 takes the file and some scratch)
+        assert r["scratch"] <= 2048 and r["lds"] <= 20 * 1024, (k, r)
 
 
 def test_shipped_actor_kernels_keep_their_weight_ring_and_two_tiles_per_cu():
