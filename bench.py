@@ -255,6 +255,29 @@ def cpu_baseline(seconds_budget=12.0):
     for k in range(40):
         env.step(acts[k])
     c_rate = 40 * E * 5 / (time.perf_counter() - t0)
+    # the same two CPU programmes with the barrier QP solved as the reference's stack solves it (the restated cvxopt iterate,
+    # oracle/rps_restated/cvxopt_restated.py / oracle_core.h barrier_qp_ipm): the closest thing to the reference's real cost
+    # per step that can be timed here -- real cvxopt is C behind Python, so the truth lies between these two figures
+    cfg_ip = dict(cfg, barrier_solver="cvxopt")
+    port_ip = np_port.make_port("PredatorCapturePrey", cfg_ip)
+    port_ip.reset()
+    n_ip, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 4.0:
+        for _ in range(10):
+            _, _, d, _ = port_ip.step(list(rng.randint(0, 5, size=5)))
+            if d[0]:
+                port_ip.reset()
+        n_ip += 10
+    py_ip_rate = n_ip * 5 / (time.perf_counter() - t0)
+    np_port.make_port("PredatorCapturePrey", cfg)  # the solver switch is module state: back to the default
+    env_ip = OracleVecEnv("PredatorCapturePrey", cfg_ip, E, dtype=np.float64)
+    for e in range(E):
+        port.reset()
+        env_ip.set_state(e, poses=port.agent_poses, prey_loc=port.prey_loc)
+    t0 = time.perf_counter()
+    for k in range(10):
+        env_ip.step(acts[k])
+    c_ip_rate = 10 * E * 5 / (time.perf_counter() - t0)
     # under rocprofv3 the profiler's preloaded library has already initialised the GPU in this process:
     # no child processes then (each would be an exec after GPU initialisation)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ)
@@ -279,7 +302,10 @@ def cpu_baseline(seconds_budget=12.0):
                                     f"job may use, 8 s" if not profiled else "skipped under rocprofv3 (no child processes)"},
             "gpu_share_16_cores": {"value": share_rate, "cores": share, "kind": "port"},
             "c_oracle_f64_1core": c_rate, "c_oracle_f64_all_cores": {"value": c_all, "cores": n_proc},
-            "c_oracle_f64_gpu_share": {"value": c_share, "cores": share}}
+            "c_oracle_f64_gpu_share": {"value": c_share, "cores": share},
+            "interior_point_mode_1core": {"port": py_ip_rate, "c_oracle_f64": c_ip_rate, "unit": "agent-steps/s",
+                                          "sample": f"{n_ip} env-steps of the NumPy port (4 s) / 10 x {E} env-steps of the C "
+                                                    f"oracle, barrier_solver: cvxopt (restated iterate, rps' options)"}}
 
 
 SATURATED_ENVS = 524288
@@ -417,9 +443,11 @@ def actor_leg(dev, E=4096, N=4, D=16, H=128, A=5, bursts=7, reps=100):
     """Side measurement (not `value`): the fused policy-inference kernel of row f3 (csrc/actor_mfma.hip, rg_actor_forward) at
     the evaluation loop's shape -- PredatorCapturePrey's zoo actor: 4096 envs x 4 agents, 16 observation floats + agent id,
     GRU hidden 128, 5 actions, random weights -- with its own roofline.  The bound is the matrix cores, and `frac` prices the launch as
-    what it issues: the GRU's products run as six bfloat16 plane products each (float32 = three bfloat16 planes, robogym.h
-    rg_actor_pack_gru_bf16x3), counted as bfloat16 MFMA flops against the dense bfloat16 peak.  `f32_equivalent_*` is the network's
-    own arithmetic (multiply-adds x 2 of fc1 + the two GRU matrices + fc2) against the float32 MFMA peak -- the side figure."""
+    what it issues.  Default form (round 5): float32 = two binary16 planes, THREE plane products per float32 product (robogym.h
+    rg_actor_pack_gru_f16x2), counted as binary16 MFMA flops against the dense binary16 / bfloat16 peak.  The round-4 form (three
+    bfloat16 planes, six products) is timed beside it: it issues twice the matrix-core work, so its `frac` is HIGHER and its launch
+    LONGER -- the figure to compare across forms is `ms_per_launch`.  `f32_equivalent_*` is the network's own arithmetic
+    (multiply-adds x 2 of fc1 + the two GRU matrices + fc2) against the float32 MFMA peak -- the side figure."""
     import torch
     from marbler_amd.evaluate import BatchedActor
     g = torch.Generator().manual_seed(3)
@@ -427,37 +455,43 @@ def actor_leg(dev, E=4096, N=4, D=16, H=128, A=5, bursts=7, reps=100):
     I = D + N
     sd = {"fc1.weight": r(H, I), "fc1.bias": r(H), "rnn.weight_ih": r(3 * H, H), "rnn.weight_hh": r(3 * H, H), "rnn.bias_ih": r(3 * H),
           "rnn.bias_hh": r(3 * H), "fc2.weight": r(A, H), "fc2.bias": r(A)}
-    actor = BatchedActor(sd, N, device=dev)
     obs = torch.rand(E, N, D, device=dev)
-    hidden = torch.zeros(E, N, H, device=dev)
     q = torch.empty(E, N, A, device=dev)
     act = torch.empty(E, N, dtype=torch.int32, device=dev)
-    for _ in range(20):
-        actor.forward_fused(obs, hidden, q_out=q, actions_out=act)
-    torch.cuda.synchronize(dev)
-    times = []
-    for _ in range(bursts):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            actor.forward_fused(obs, hidden, q_out=q, actions_out=act)
-        b.record()
-        torch.cuda.synchronize(dev)
-        times.append(a.elapsed_time(b) / reps)
-    ms = sorted(times)[len(times) // 2]
     flop = 2.0 * E * N * (I * H + 2 * 3 * H * H + H * A)
-    gru_bf16_flop = 6 * 2.0 * E * N * (2 * 3 * H * H)      # six plane products per float32 product, as issued
-    tf = flop / (ms * 1e-3) / 1e12
-    bf16_tf = gru_bf16_flop / (ms * 1e-3) / 1e12
-    return {"kernel": "rg::actor_kernel<128, split> (rg_actor_forward, GRU on three bfloat16 planes)", "rows": E * N, "hidden": H, "ms_per_launch": ms,
-            "ms_per_launch_min": min(times), "flops_per_launch": flop,
-            # priced as what the launch ISSUES: bfloat16 MFMA work against the dense bfloat16 peak; the network's own float32
-            # arithmetic against the float32 MFMA peak is the side figure (it flatters: six cheap plane products per product)
-            "roofline": {"bound": "mfma", "achieved": bf16_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": bf16_tf / BF16_MFMA_PEAK_TFLOPS,
-                         "peak_kind": "dense bfloat16 MFMA, as issued (the GRU's float32 products run as six bfloat16 plane products each; "
-                                      "fc1 / fc2 are 28 float32 MFMAs per wave, < 3 % of the cycles, not counted)",
-                         "f32_equivalent_TFLOPs": tf, "f32_equivalent_frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS},
-            "agent_rows_per_s": E * N / (ms * 1e-3)}
+    forms = {}
+    for form, products in (("f16x2", 3), ("bf16x3", 6)):
+        actor = BatchedActor(sd, N, device=dev, pack_gru=form)
+        hidden = torch.zeros(E, N, H, device=dev)
+        for _ in range(20):
+            actor.forward_fused(obs, hidden, q_out=q, actions_out=act)
+        torch.cuda.synchronize(dev)
+        times = []
+        for _ in range(bursts):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                actor.forward_fused(obs, hidden, q_out=q, actions_out=act)
+            b.record()
+            torch.cuda.synchronize(dev)
+            times.append(a.elapsed_time(b) / reps)
+        ms = sorted(times)[len(times) // 2]
+        issued = products * 2.0 * E * N * (2 * 3 * H * H) / (ms * 1e-3) / 1e12      # plane products per float32 product, as issued
+        forms[form] = {"ms_per_launch": ms, "ms_per_launch_min": min(times), "plane_products_per_f32_product": products,
+                       "issued_TFLOPs": issued, "frac_of_dense_16bit_mfma_peak": issued / BF16_MFMA_PEAK_TFLOPS,
+                       "f32_equivalent_TFLOPs": flop / (ms * 1e-3) / 1e12}
+    d = forms["f16x2"]
+    return {"kernel": "rg::actor_kernel<128, 2> (rg_actor_forward, GRU on two binary16 planes)", "rows": E * N, "hidden": H, "ms_per_launch": d["ms_per_launch"],
+            "ms_per_launch_min": d["ms_per_launch_min"], "flops_per_launch": flop,
+            # priced as what the launch ISSUES: 16-bit MFMA work against the dense 16-bit peak; the network's own float32
+            # arithmetic against the float32 MFMA peak is the side figure (it flatters: three cheap plane products per product)
+            "roofline": {"bound": "mfma", "achieved": d["issued_TFLOPs"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": d["frac_of_dense_16bit_mfma_peak"],
+                         "peak_kind": "dense binary16 MFMA (= the bfloat16 rate), as issued (the GRU's float32 products run as three binary16 plane "
+                                      "products each; fc1 / fc2 are 28 float32 MFMAs per wave, not counted)",
+                         "f32_equivalent_TFLOPs": d["f32_equivalent_TFLOPs"],
+                         "f32_equivalent_frac_of_f32_mfma_peak": d["f32_equivalent_TFLOPs"] / F32_MFMA_PEAK_TFLOPS},
+            "forms": forms, "agent_rows_per_s": E * N / (d["ms_per_launch"] * 1e-3)}
 
 
 def launch_ranks(args):
@@ -552,7 +586,7 @@ def dry_run(args, rank, world, collective):
         per_rank = [float(v[0]) for v in everyone]
         elapsed = max(per_rank) * 1e-3
     zeros_f, zeros_i = torch.zeros(count), torch.full((count,), rank, dtype=torch.int32)
-    stats = rgdist.gather_episode_stats(zeros_f, zeros_i, zeros_i.clone(), dst=0)
+    stats = rgdist.gather_episode_stats(zeros_f, zeros_i, zeros_i.clone(), dst=0, total_envs=world * E)
     if rank == 0:
         import hashlib
         out = {"metric": "env agent-steps/sec", "value": None, "unit": "agent-steps/s", "n_gpus": world, "steps": 0,
@@ -728,7 +762,7 @@ def main():
     kernel_ms_median = durs[len(durs) // 2]
 
     # episode statistics gathered to rank 0 (RCCL all_gather over xGMI when world > 1)
-    stats = rgdist.gather_episode_stats(env.done_return_sum, env.done_count, env.done_steps_sum, dst=0)
+    stats = rgdist.gather_episode_stats(env.done_return_sum, env.done_count, env.done_steps_sum, dst=0, total_envs=world * E)
 
     if rank == 0:
         total_agent_steps = world * E * N * K

@@ -28,7 +28,8 @@ extern "C" {
 #endif
 
 /* 6 (round 5): rg_scenario_params ends in the barrier-QP solver selection (qp_mode + cvxopt's options): RG_QP_CVXOPT computes the
- * interior-point iterate the reference's stack computes (utilities/controller.py:13-16,23) instead of the exact projection.
+ * interior-point iterate the reference's stack computes (utilities/controller.py:13-16,23) instead of the exact projection;
+ * rg_step_io.zero_obs_on_end; + rg_actor_forward_explore(), rg_actor_pack_gru_f16x2() and rg_actor_weights.gru_packed == 3.
  * 5 (round 4): + rg_actor_pack_gru_bf16x3() and rg_actor_weights.gru_packed == 2; rg_rollout takes every shape (no E*N*D % 4
  * rule); the one-lane-per-env step kernel covers N <= 6. */
 #define RG_ABI_VERSION 6
@@ -256,7 +257,8 @@ typedef struct {
     const float *w2, *b2;   /* [S][A][H], [S][A] */
     int32_t n_sets, input_dim, hidden_dim, n_actions, use_rnn;
     int32_t gru_packed;     /* 0: wih / whh in torch's layout; 1: the float32 streaming order written by rg_actor_pack_gru;
-                               2: three bfloat16 planes written by rg_actor_pack_gru_bf16x3 (6 bytes per weight) */
+                               2: three bfloat16 planes written by rg_actor_pack_gru_bf16x3 (6 bytes per weight);
+                               3: two binary16 planes written by rg_actor_pack_gru_f16x2 (4 bytes per weight) */
 } rg_actor_weights;
 
 /* One actor step (misc.py:160-170: `actor(obs, hs)` then arg-max).  obs [E][N][D]; with
@@ -268,6 +270,13 @@ typedef struct {
 int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
                      int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden, float *q,
                      int32_t *actions, void *hip_stream);
+/* The same launch with the epsilon-greedy selection of EPyMARL's action selector (components/action_selectors.py, external to
+ * the reference: its runners explore this way during training) folded in: explore_u [E][N] holds one uniform draw in [0, 1) per
+ * agent; with k = (int)(u * (n_actions / epsilon)) in binary32, the action is k when k < n_actions (that is u < epsilon, and k is
+ * then uniform over the actions) and the greedy action otherwise.  epsilon in [1e-6, 1]; actions must not be NULL. */
+int rg_actor_forward_explore(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
+                             int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden, float *q,
+                             int32_t *actions, const float *explore_u, float epsilon, void *hip_stream);
 /* Optional, once per actor: reorder a GRU weight array ([S][3H][H], torch layout) into the order the
  * kernel streams it (1 KB per load instruction instead of 64 scattered 16-byte pieces).  dst: a device
  * buffer of the same size; use it as wih / whh with gru_packed = 1. */
@@ -279,6 +288,15 @@ int rg_actor_pack_gru(const float *src, int32_t n_sets, int32_t hidden_dim, floa
  * way on the fly; the three products of order 2^-24 are left out, which keeps the error below the rounding error of a
  * float32 dot product of the same length (rnn_agent.py:24 `self.rnn(x, h_in)` evaluated in float32 is the reference). */
 int rg_actor_pack_gru_bf16x3(const float *src, int32_t n_sets, int32_t hidden_dim, void *dst, void *hip_stream);
+/* The same matrix as TWO binary16 planes -- hi = binary16(w), lo' = binary16(2^11 (w - hi)): w = hi + 2^-11 lo' up to 2^-22 |w|
+ * -- in the order the kernel streams them.  dst: 4 bytes per weight = the size of src, 16-byte aligned; use it as wih / whh with
+ * gru_packed = 3.  A float32 product is then THREE plane products on the binary16 matrix cores (hi hi into one accumulator, the
+ * two cross products into a second that joins it scaled by 2^-11), the hidden state and fc1's output being split the same way on
+ * the fly: half the matrix-core time of the three-plane form, error at the level of a float32 GEMM's own roundings (measured
+ * max 3.9e-7 against 9.5e-7 on 128-long dot products).  Range: binary16's -- activations above 65 504 saturate (the hidden state
+ * is in [-1, 1], fc1's output a ReLU of the observation's affine image); below 2^-14 the first plane is a binary16 denormal, which
+ * the matrix cores take as it is. */
+int rg_actor_pack_gru_f16x2(const float *src, int32_t n_sets, int32_t hidden_dim, void *dst, void *hip_stream);
 const char *rg_actor_last_error(void);
 
 #ifdef __cplusplus

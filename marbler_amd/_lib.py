@@ -82,7 +82,7 @@ class RgActorWeights(C.Structure):
 
 EXPORTS = ("rg_abi_version", "rg_last_error", "rg_sizeof_params", "rg_sizeof_state", "rg_sizeof_step_io", "rg_next_init_stride",
            "rg_create", "rg_destroy", "rg_bind_state", "rg_set_stream", "rg_reset", "rg_step", "rg_rollout", "rg_get_obs", "rg_step_kernel",
-           "rg_actor_forward", "rg_actor_pack_gru", "rg_actor_pack_gru_bf16x3", "rg_actor_last_error")
+           "rg_actor_forward", "rg_actor_forward_explore", "rg_actor_pack_gru", "rg_actor_pack_gru_bf16x3", "rg_actor_pack_gru_f16x2", "rg_actor_last_error")
 
 _lib = None
 
@@ -122,10 +122,15 @@ def load():
     lib.rg_actor_forward.argtypes = [C.POINTER(RgActorWeights), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rg_actor_forward.restype = C.c_int
+    lib.rg_actor_forward_explore.argtypes = [C.POINTER(RgActorWeights), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    lib.rg_actor_forward_explore.restype = C.c_int
     lib.rg_actor_pack_gru.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_actor_pack_gru.restype = C.c_int
     lib.rg_actor_pack_gru_bf16x3.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_actor_pack_gru_bf16x3.restype = C.c_int
+    lib.rg_actor_pack_gru_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rg_actor_pack_gru_f16x2.restype = C.c_int
     lib.rg_actor_last_error.restype = C.c_char_p
     for f in (lib.rg_destroy, lib.rg_bind_state, lib.rg_set_stream, lib.rg_reset, lib.rg_step, lib.rg_rollout, lib.rg_get_obs,
               lib.rg_sizeof_params, lib.rg_sizeof_state, lib.rg_sizeof_step_io):

@@ -69,6 +69,24 @@ __device__ __forceinline__ void split8(const float4 &lo4, const float4 &hi4, bf1
     pl = __builtin_bit_cast(bf16x8, l);
 }
 
+// ---- float32 carried as TWO binary16 planes (gru_packed == 3; round 5): half the matrix-core time of the three-plane form.
+// x = hi + lo with hi = x rounded to binary16 (11 significant bits) and lo = x - hi (exact, below 2^-11 |x|); lo is
+// carried SCALED by 2^11 -- lo' = binary16(2048 lo), again 11 significant bits, well inside binary16's exponent range wherever
+// hi is -- so what is dropped is below 2^-22 |x|.  A product x w is hi hi + (hi lo' + lo' hi) 2^-11 + O(2^-22): THREE plane
+// products on v_mfma_f32_32x32x16_f16 (the same 32 cycles for K = 16 as the bfloat16 instruction), the two cross products into
+// a second accumulator that joins the first with one multiply-add in the gate arithmetic.  Measured on 2048 x 128 x 384 random
+// operands against the exact product: max 3.9e-7, rms 5.6e-8 -- a float32 GEMM of the same operands: 9.5e-7 / 7.5e-8.
+// Range: binary16's.  Activations are the hidden state (in [-1, 1]) and fc1's ReLU output; |x| > 65504 saturates (never inf).
+// Below 2^-14 hi is a binary16 DENORMAL (spacing 2^-24) and lo' the 11 bits after it: conversions and the matrix cores take
+// denormal operands as they are on gfx950 (round 5: with them flushed -- s_setreg MODE.FP_DENORM -- a hidden state of 3e-5 kept 11
+// bits in all, and products against large weights were off by 2e-4; tests/test_gpu_actor.py holds the case).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_LO_SCALE = 2048.0f, F16_LO_UNSCALE = 1.0f / 2048.0f;
+// The activations are split where they are PRODUCED (fc1's epilogue, the hidden state's staging copy: split1 below), once per tile,
+// into plane images in LDS; the products' loop reads 16-byte operands and runs no conversion (split by every wave at every K step,
+// 64 conversion instructions per step stood between the MFMAs: 52 cycles per MFMA against the pipe's 32).
+
 constexpr int TM = 32;        // agent rows per wavefront
 constexpr int MAX_IP = 64;    // padded input width (multiple of 8)
 
@@ -79,6 +97,8 @@ struct ActorArgs {
     float *hidden;          // [E][N][H] in/out
     float *q;               // [E][N][A] or NULL
     int32_t *actions;       // [E][N] or NULL
+    const float *explore_u; // [E][N] uniforms in [0, 1) or NULL: epsilon-greedy selection (rg_actor_forward_explore)
+    float explore_scale;    // n_actions / epsilon
     int32_t E, N, D, append_agent_id, ip;  // ip = padded input width
 };
 
@@ -107,7 +127,17 @@ __device__ __forceinline__ int swz(int i, int k) { return i * H + ((((k >> 2) ^ 
 template <int H>
 __device__ __forceinline__ int swz4(int i, int k4) { return i * H + ((k4 ^ (i & 7)) << 2); }
 
-template <int H, bool SPLIT>   // SPLIT: the GRU's products on bfloat16 planes (gru_packed == 2)
+// binary16 plane images [TM][H] (pitch H halves): the 16-byte block b8 = k / 8 of row i lives at block b8 ^ (i & 7) -- the eight lanes
+// of an LDS lane group read one logical block of eight consecutive rows: eight physical blocks, all banks
+template <int H>
+__device__ __forceinline__ int swz8(int i, int b8) { return i * H + ((b8 ^ (i & 7)) << 3); }
+// one value -> its two planes, rounded to nearest (the activations are split where they are PRODUCED, once per tile)
+__device__ __forceinline__ void split1(float x, _Float16 &hi, _Float16 &lo) {
+    hi = static_cast<_Float16>(x);
+    lo = static_cast<_Float16>((x - static_cast<float>(hi)) * F16_LO_SCALE);
+}
+
+template <int H, int SPLIT>   // SPLIT: the GRU's products on 1: three bfloat16 planes (gru_packed == 2), 2: two binary16 planes (gru_packed == 3)
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256 registers (VGPR + AGPR): two tiles per CU, one's serial phases under the other's MFMAs
 __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
 #ifdef RG_ACTOR_STAMPS
@@ -116,9 +146,13 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #endif
     constexpr int NW = H / 32;  // wavefronts per tile
     constexpr int NTHREADS = 64 * NW;
-    __shared__ __attribute__((aligned(16))) float lds[2 * TM * H];
+    // SPLIT == 2: a third image.  Y is then held as its two binary16 planes (in the place of its float32 image: the same size), the
+    // old hidden state as float32 (the blend with the new one wants it exact) AND as planes in the third image
+    __shared__ __attribute__((aligned(16))) float lds[(SPLIT == 2 ? 3 : 2) * TM * H];
     float *const Y = lds;            // fc1's output (A operand of the GRU), later fc2's partial sums
     float *const Hs = lds + TM * H;  // the old hidden state (A operand), then the new one
+    _Float16 *const Yp = reinterpret_cast<_Float16 *>(lds);                // planes: hi at 0, lo' at TM * H halves
+    _Float16 *const Hp = reinterpret_cast<_Float16 *>(lds + (SPLIT == 2 ? 2 : 0) * TM * H);
     const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6, half = lane >> 5, col = lane & 31;
     const int E = a.E, N = a.N, A = a.w.n_actions, I = a.w.input_dim, IP = a.ip;
     const bool shared = a.w.n_sets == 1;
@@ -274,12 +308,36 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     RG_HSTAMP(4);  // (head) fc1's products and its bias have arrived
 #endif
     __syncthreads();   // every wave is done with the staged operands: their place becomes Y and the old hidden state
+    if constexpr (SPLIT == 2) {   // the GRU's A operands as binary16 planes, split here once (not by every wave at every k step)
 #pragma unroll
-    for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = fmaxf(acc[r_] + b1, 0.0f);
+        for (int r_ = 0; r_ < 16; ++r_) {
+            _Float16 hi, lo;
+            split1(fmaxf(acc[r_] + b1, 0.0f), hi, lo);
+            const int at = swz8<H>(crow(r_), n >> 3) + (n & 7);
+            Yp[at] = hi;
+            Yp[TM * H + at] = lo;
+        }
+    } else {
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = fmaxf(acc[r_] + b1, 0.0f);
+    }
 #pragma unroll
     for (int m = 0; m < HV; ++m) {
         const int idx = tid + NTHREADS * m, i = idx / (H / 4), k4 = idx % (H / 4);
-        *reinterpret_cast<float4 *>(&Hs[swz4<H>(i, k4)]) = keep[m] ? hv[m] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 hval = keep[m] ? hv[m] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *reinterpret_cast<float4 *>(&Hs[swz4<H>(i, k4)]) = hval;
+        if constexpr (SPLIT == 2) {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 hi, lo;
+            _Float16 a_, b_;
+            split1(hval.x, a_, b_), hi[0] = a_, lo[0] = b_;
+            split1(hval.y, a_, b_), hi[1] = a_, lo[1] = b_;
+            split1(hval.z, a_, b_), hi[2] = a_, lo[2] = b_;
+            split1(hval.w, a_, b_), hi[3] = a_, lo[3] = b_;
+            const int at = swz8<H>(i, k4 >> 1) + 4 * (k4 & 1);
+            *reinterpret_cast<f16x4 *>(&Hp[at]) = hi;
+            *reinterpret_cast<f16x4 *>(&Hp[TM * H + at]) = lo;
+        }
     }
     RG_HSTAMP(5);  // (head) Y and the old hidden state written to LDS
     __syncthreads();
@@ -305,7 +363,74 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 
     // ---- recurrent layer
     float hn[16];       // the new hidden state in accumulator layout (the old one is still an operand)
-    if (a.w.use_rnn) {  // torch.nn.GRUCell: gates r, z, n in that order
+    if (a.w.use_rnn && SPLIT == 2) {   // two binary16 planes: three products per float32 product
+        if constexpr (SPLIT == 2) {
+            const int j = cb * 32 + col;
+            const float br = Bih[j] + Bhh[j], bz = Bih[H + j] + Bhh[H + j], bin = Bih[2 * H + j], bhn = Bhh[2 * H + j];
+            __builtin_amdgcn_sched_barrier(0);
+            // accumulators: 0 = r, 1 = z (input and recurrent products meet in one), 2 = the input half of n, 3 = its recurrent
+            // half (r multiplies that one); am: hi hi, ac: the cross products at scale 2^11
+            floatx16 am[4], ac[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                am[g] = zero16();
+                ac[g] = zero16();
+            }
+            // the stream: [cb][ks][gate][plane][lane][8] binary16, groups (ks, gate, matrix) of two 16-byte operands and three
+            // MFMAs; PD groups in flight ahead, held in place by the fences (see the three-plane form)
+            constexpr int KS = H / 16, NG = KS * 6;
+            const size_t set_off = static_cast<size_t>(set) * 3 * H * H * 2;
+            const uint16_t *Pih = reinterpret_cast<const uint16_t *>(a.w.wih) + set_off, *Phh = reinterpret_cast<const uint16_t *>(a.w.whh) + set_off;
+            auto load_w = [&](int t, u32x4 (&wl)[2]) {
+                const int ks = t / 6, g = (t % 6) >> 1, hh = t & 1;
+                const uint16_t *src = (hh ? Phh : Pih) + ((static_cast<size_t>((cb * KS + ks) * 3 + g) * 2) * 64 + lane) * 8;
+                wl[0] = *reinterpret_cast<const u32x4 *>(src);
+                wl[1] = *reinterpret_cast<const u32x4 *>(src + 64 * 8);
+            };
+            constexpr int PD = 2, RING = PD + 1;   // (3 and 4 in flight measured no faster: 20.4 / 20.9 / 20.5 us)
+            u32x4 wq[RING][2];
+#pragma unroll
+            for (int t = 0; t < PD; ++t) load_w(t, wq[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 yh, yl, hh_, hl_;
+#pragma unroll
+            for (int t = 0; t < NG; ++t) {
+                const int ks = t / 6, g = (t % 6) >> 1, hh = t & 1;
+                if (t + PD < NG) load_w(t + PD, wq[(t + PD) % RING]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t % 6 == 0) {   // this step's activations for all six groups: k = 16 ks + 8 half + e of tile row `col`
+                    const int at = swz8<H>(col, 2 * ks + half);
+                    yh = *reinterpret_cast<const f16x8 *>(&Yp[at]);
+                    yl = *reinterpret_cast<const f16x8 *>(&Yp[TM * H + at]);
+                    hh_ = *reinterpret_cast<const f16x8 *>(&Hp[at]);
+                    hl_ = *reinterpret_cast<const f16x8 *>(&Hp[TM * H + at]);
+                }
+                const f16x8 wh = __builtin_bit_cast(f16x8, wq[t % RING][0]), wl = __builtin_bit_cast(f16x8, wq[t % RING][1]);
+                const f16x8 xh = hh ? hh_ : yh, xl = hh ? hl_ : yl;
+                const int ai = g < 2 ? g : 2 + hh;
+                ac[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, ac[ai], 0, 0, 0);
+                ac[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, ac[ai], 0, 0, 0);
+                am[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, am[ai], 0, 0, 0);
+            }
+#ifdef RG_ACTOR_STAMPS
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(am[g]), "v"(ac[g]));
+#ifndef RG_ACTOR_STAMPS_FC1
+            RG_ASTAMP(2);  // GRU products
+#endif
+#endif
+            request_fc2();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float rg_ = sigmoidf_(__builtin_fmaf(ac[0][r], F16_LO_UNSCALE, am[0][r]) + br);
+                const float zg = sigmoidf_(__builtin_fmaf(ac[1][r], F16_LO_UNSCALE, am[1][r]) + bz);
+                const float ni = __builtin_fmaf(ac[2][r], F16_LO_UNSCALE, am[2][r]) + bin;
+                const float nh = __builtin_fmaf(ac[3][r], F16_LO_UNSCALE, am[3][r]) + bhn;
+                const float ng = tanhf_(ni + rg_ * nh);
+                hn[r] = (1.0f - zg) * ng + zg * Hs[swz<H>(crow(r), j)];
+            }
+        }
+    } else if (a.w.use_rnn) {  // torch.nn.GRUCell: gates r, z, n in that order
         {
             const int j = cb * 32 + col;
             floatx16 gi[3], gh[3];
@@ -314,7 +439,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 bir = Bih[j], biz = Bih[H + j], bin = Bih[2 * H + j];
                 bhr = Bhh[j], bhz = Bhh[H + j], bhn = Bhh[2 * H + j];
             };
-            if constexpr (SPLIT) {   // requested ahead of the products: behind them the gates would start with a trip to L2
+            if constexpr (SPLIT == 1) {   // requested ahead of the products: behind them the gates would start with a trip to L2
                 request_biases();    // (the float32-MFMA form has no registers to spare for that)
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -323,7 +448,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 gi[g] = zero16();
                 gh[g] = zero16();
             }
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 1) {
                 // K in steps of 16: lane (col, half) holds k = 16 ks + 8 half + e, e = 0..7, of its row (activations: tile row
                 // `col`; weights: gate row g H + j) -- three 16-byte operands per matrix and step, written in exactly this
                 // order by rg_actor_pack_gru_bf16x3: [cb][ks][gate][plane][lane][8].  Groups (ks, gate, matrix) are
@@ -373,7 +498,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                     if (hh) gh[g] = acc;
                     else gi[g] = acc;
                 }
-            } else {
+            } else if constexpr (SPLIT == 0) {
             // The weight stream: lane (col, half) owns row g H + j of each gate matrix and, of that row, the
             // k range of its half -- consumed in chunks of 32 floats = one 128-byte line per lane, eight
             // float4 loads issued together, so a line is used up while it is hot (with 16 B per visit the
@@ -426,7 +551,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             RG_ASTAMP(2);  // GRU products
 #endif
 #endif
-            if constexpr (!SPLIT) request_biases();
+            if constexpr (SPLIT != 1) request_biases();
             request_fc2();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -527,7 +652,13 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             }
         }
         arg = static_cast<unsigned>(arg) >= static_cast<unsigned>(A) ? 0 : arg;
-        if (ok && sub == 0 && a.actions) a.actions[r] = arg;
+        if (ok && sub == 0 && a.actions) {
+            if (a.explore_u) {  // u < epsilon  <=>  u * (A / epsilon) < A: that product's integer part is the uniform action
+                const int k = static_cast<int>(a.explore_u[r] * a.explore_scale);
+                if (static_cast<unsigned>(k) < static_cast<unsigned>(A)) arg = k;
+            }
+            a.actions[r] = arg;
+        }
     }
     {
         const int j = cb * 32 + col;
@@ -599,9 +730,49 @@ __global__ void pack_gru_bf16x3_kernel(const float *src, uint16_t *dst, int n_se
     }
 }
 
+// torch layout [S][3H][H] float32 -> two binary16 planes (hi, 2^11 lo: see split1) in the streaming order
+// [S][cb][ks][gate][plane][lane = (half, col)][8]: 4 bytes per weight.  Round to nearest here (the weights are split once).
+__global__ void pack_gru_f16x2_kernel(const float *src, uint16_t *dst, int n_sets, int H) {
+    const int nks = H / 16, ncb = H / 32;
+    const size_t total = static_cast<size_t>(n_sets) * 3 * H * H;
+    for (size_t o = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        size_t r = o;
+        const int e = r % 8; r /= 8;
+        const int lane = r % 64; r /= 64;
+        const int g = r % 3; r /= 3;
+        const int ks = r % nks; r /= nks;
+        const int cb = r % ncb; r /= ncb;
+        const int s = static_cast<int>(r);
+        const int half = lane >> 5, col = lane & 31;
+        const int row = g * H + cb * 32 + col, k = ks * 16 + half * 8 + e;
+        const float w = src[(static_cast<size_t>(s) * 3 * H + row) * H + k];
+        const _Float16 hi = static_cast<_Float16>(w);
+        const float rest = (w - static_cast<float>(hi)) * F16_LO_SCALE;
+        const _Float16 lo = static_cast<_Float16>(rest);
+        const size_t base = ((((static_cast<size_t>(s) * ncb + cb) * nks + ks) * 3 + g) * 2) * 64 * 8 + static_cast<size_t>(lane) * 8 + e;
+        dst[base] = __builtin_bit_cast(uint16_t, hi);
+        dst[base + 64 * 8] = __builtin_bit_cast(uint16_t, lo);
+    }
+}
+
 }  // namespace rg
 
 static thread_local char g_actor_err[256] = "";
+
+extern "C" int rg_actor_pack_gru_f16x2(const float *src, int32_t n_sets, int32_t hidden_dim, void *dst, void *hip_stream) {
+    if (!src || !dst || n_sets < 1 || (hidden_dim != 64 && hidden_dim != 128)) {
+        snprintf(g_actor_err, sizeof(g_actor_err), "rg_actor_pack_gru_f16x2: NULL array, n_sets < 1 or hidden_dim not 64 / 128");
+        return -1;
+    }
+    if (reinterpret_cast<uintptr_t>(dst) & 15u) {
+        snprintf(g_actor_err, sizeof(g_actor_err), "rg_actor_pack_gru_f16x2: dst must be 16-byte aligned");
+        return -9;
+    }
+    hipLaunchKernelGGL(rg::pack_gru_f16x2_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), src,
+                       static_cast<uint16_t *>(dst), n_sets, hidden_dim);
+    return hipGetLastError() == hipSuccess ? 0 : -30;
+}
 
 extern "C" int rg_actor_pack_gru_bf16x3(const float *src, int32_t n_sets, int32_t hidden_dim, void *dst, void *hip_stream) {
     if (!src || !dst || n_sets < 1 || (hidden_dim != 64 && hidden_dim != 128)) {
@@ -632,15 +803,15 @@ extern "C" const char *rg_actor_last_error(void) { return g_actor_err; }
 #ifdef RG_ACTOR_STAMPS  // diagnostic build: what the runtime says about co-resident workgroups per CU
 extern "C" int rg_actor_occupancy(int hidden_dim) {
     int n = -1;
-    if (hidden_dim == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<64, true>, 128, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<128, true>, 256, 0);
+    if (hidden_dim == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<64, 1>, 128, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<128, 1>, 256, 0);
     return n;
 }
 #endif
 
-extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
-                                int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden,
-                                float *q, int32_t *actions, void *hip_stream) {
+static int actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
+                         int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden,
+                         float *q, int32_t *actions, const float *explore_u, float epsilon, void *hip_stream) {
     auto fail = [](int code, const char *msg) {
         snprintf(g_actor_err, sizeof(g_actor_err), "%s", msg);
         return code;
@@ -650,9 +821,11 @@ extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int
     if (w->use_rnn && (!w->whh || !w->bhh)) return fail(-2, "GRU weights whh / bhh are NULL");
     if (w->hidden_dim != 64 && w->hidden_dim != 128) return fail(-3, "hidden_dim must be 64 or 128 (the reference's actors)");
     if (w->n_actions < 1 || w->n_actions > 32) return fail(-4, "n_actions must be in 1..32");
-    if (w->gru_packed < 0 || w->gru_packed > 2) return fail(-10, "gru_packed must be 0 (torch layout), 1 (rg_actor_pack_gru) or 2 (rg_actor_pack_gru_bf16x3)");
+    if (w->gru_packed < 0 || w->gru_packed > 3) return fail(-10, "gru_packed must be 0 (torch layout), 1 (rg_actor_pack_gru), 2 (rg_actor_pack_gru_bf16x3) or 3 (rg_actor_pack_gru_f16x2)");
     if (w->n_sets != 1 && w->n_sets != n_agents) return fail(-5, "n_sets must be 1 (shared) or n_agents");
     if (num_envs < 1 || n_agents < 1 || obs_dim < 1) return fail(-6, "num_envs, n_agents, obs_dim must be >= 1");
+    if (explore_u && !(epsilon >= 1e-6f && epsilon <= 1.0f)) return fail(-11, "epsilon must be in [1e-6, 1] when explore_u is given");
+    if (explore_u && !actions) return fail(-11, "explore_u without an actions array");
     const int in_dim = obs_dim + (append_agent_id ? n_agents : 0);
     if (in_dim != w->input_dim) return fail(-7, "obs_dim (+ n_agents with append_agent_id) != the actor's input_dim");
     const int ip = (in_dim + 7) / 8 * 8;
@@ -667,6 +840,8 @@ extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int
     a.hidden = hidden;
     a.q = q;
     a.actions = actions;
+    a.explore_u = explore_u;
+    a.explore_scale = explore_u ? static_cast<float>(w->n_actions) / epsilon : 0.0f;
     a.E = num_envs;
     a.N = n_agents;
     a.D = obs_dim;
@@ -675,15 +850,32 @@ extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int
     const int tiles = w->n_sets == 1 ? (num_envs * n_agents + rg::TM - 1) / rg::TM
                                      : n_agents * ((num_envs + rg::TM - 1) / rg::TM);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const bool split = w->use_rnn && w->gru_packed == 2;
+    const int split = !w->use_rnn ? 0 : w->gru_packed == 2 ? 1 : w->gru_packed == 3 ? 2 : 0;
     if (w->hidden_dim == 64) {
-        if (split) hipLaunchKernelGGL((rg::actor_kernel<64, true>), dim3(tiles), dim3(128), 0, stream, a);
-        else hipLaunchKernelGGL((rg::actor_kernel<64, false>), dim3(tiles), dim3(128), 0, stream, a);
+        if (split == 2) hipLaunchKernelGGL((rg::actor_kernel<64, 2>), dim3(tiles), dim3(128), 0, stream, a);
+        else if (split == 1) hipLaunchKernelGGL((rg::actor_kernel<64, 1>), dim3(tiles), dim3(128), 0, stream, a);
+        else hipLaunchKernelGGL((rg::actor_kernel<64, 0>), dim3(tiles), dim3(128), 0, stream, a);
     } else {
-        if (split) hipLaunchKernelGGL((rg::actor_kernel<128, true>), dim3(tiles), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((rg::actor_kernel<128, false>), dim3(tiles), dim3(256), 0, stream, a);
+        if (split == 2) hipLaunchKernelGGL((rg::actor_kernel<128, 2>), dim3(tiles), dim3(256), 0, stream, a);
+        else if (split == 1) hipLaunchKernelGGL((rg::actor_kernel<128, 1>), dim3(tiles), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((rg::actor_kernel<128, 0>), dim3(tiles), dim3(256), 0, stream, a);
     }
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(-30, hipGetErrorString(err));
     return 0;
+}
+
+extern "C" int rg_actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
+                                int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden,
+                                float *q, int32_t *actions, void *hip_stream) {
+    return actor_forward(w, num_envs, n_agents, obs, obs_dim, append_agent_id, restart, hidden, q, actions, nullptr, 0.0f,
+                         hip_stream);
+}
+
+extern "C" int rg_actor_forward_explore(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
+                                        int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden,
+                                        float *q, int32_t *actions, const float *explore_u, float epsilon,
+                                        void *hip_stream) {
+    return actor_forward(w, num_envs, n_agents, obs, obs_dim, append_agent_id, restart, hidden, q, actions, explore_u, epsilon,
+                         hip_stream);
 }

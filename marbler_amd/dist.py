@@ -71,34 +71,40 @@ def broadcast_params(params, src=0, device=None):
     return params_from_bytes(buf.cpu().numpy().tobytes())
 
 
-def gather_episode_stats(done_return_sum, done_count, done_steps_sum, dst=0):
+def gather_episode_stats(done_return_sum, done_count, done_steps_sum, dst=0, total_envs=None):
     """Gathers the per-env [E_local] statistics of every rank to `dst`: returns as float32, episode counts and
-    step totals as int64 (exact -- never through a float).  Two fixed-size collectives per call (shards are
-    equal up to one env; shorter shards are padded).  Returns (returns [E_total] f32, counts i64, steps i64) on
-    `dst`, None elsewhere.  With no process group: the inputs.
+    step totals as int64 (exact -- never through a float).  ONE fixed-size collective per call (shards are equal up to one
+    env; shorter shards are padded): the float32 returns travel as their bit patterns in a third int64 row.
+    total_envs: the job's env count when the shards are `shard(total_envs, rank, world)` (every caller in this repo): the
+    shard sizes then follow from arithmetic and the call makes no host synchronisation besides the collective itself;
+    without it one 8-byte all_gather of the sizes precedes the gather.  A reporting-interval call -- per time step it
+    would serialise the ranks; nothing in the step path calls it.
+    Returns (returns [E_total] f32, counts i64, steps i64) on `dst`, None elsewhere.  With no process group: the inputs.
     RCCL (nccl backend) has a true gather to one root; gloo on CPU does too."""
     if not dist.is_initialized():
         return done_return_sum, done_count.to(torch.int64), done_steps_sum.to(torch.int64)
     world, rank = dist.get_world_size(), dist.get_rank()
     cdev = collective_device(done_return_sum.device)
     k = done_return_sum.numel()
-    n = torch.tensor([k], dtype=torch.int64, device=cdev)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)                     # 8 bytes per rank; every rank needs the padded size
-    sizes = [int(x.item()) for x in sizes]
+    if total_envs is not None:
+        sizes = [shard(int(total_envs), r, world)[1] for r in range(world)]
+        if sizes[rank] != k:
+            raise ValueError(f"rank {rank} holds {k} envs, shard({total_envs}, {rank}, {world}) says {sizes[rank]}")
+    else:
+        n = torch.tensor([k], dtype=torch.int64, device=cdev)
+        every = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(every, n)                     # 8 bytes per rank; every rank needs the padded size
+        sizes = torch.cat(every).tolist()
     m = max(sizes)
-    f = torch.zeros(m, dtype=torch.float32, device=cdev)
-    f[:k] = done_return_sum.to(cdev)
-    i = torch.zeros(2, m, dtype=torch.int64, device=cdev)
-    i[0, :k] = done_count.to(cdev)
-    i[1, :k] = done_steps_sum.to(cdev)
-    fl = [torch.zeros_like(f) for _ in range(world)] if rank == dst else None
-    il = [torch.zeros_like(i) for _ in range(world)] if rank == dst else None
-    dist.gather(f, fl, dst=dst)
-    dist.gather(i, il, dst=dst)
+    buf = torch.zeros(3, m, dtype=torch.int64, device=cdev)
+    buf[0, :k] = done_return_sum.to(device=cdev, dtype=torch.float32).contiguous().view(torch.int32)
+    buf[1, :k] = done_count.to(cdev)
+    buf[2, :k] = done_steps_sum.to(cdev)
+    got = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, got, dst=dst)
     if rank != dst:
         return None
-    ret = torch.cat([t[:c] for t, c in zip(fl, sizes)])
-    cnt = torch.cat([t[0, :c] for t, c in zip(il, sizes)])
-    stp = torch.cat([t[1, :c] for t, c in zip(il, sizes)])
+    ret = torch.cat([t[0, :c] for t, c in zip(got, sizes)]).to(torch.int32).view(torch.float32)
+    cnt = torch.cat([t[1, :c] for t, c in zip(got, sizes)])
+    stp = torch.cat([t[2, :c] for t, c in zip(got, sizes)])
     return ret, cnt, stp

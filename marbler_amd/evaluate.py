@@ -15,6 +15,9 @@ import json
 import torch
 
 
+DEFAULT_PACK_GRU = "f16x2"   # what pack_gru=True means
+
+
 class BatchedActor(object):
     """RNNAgent / RNNNSAgent weights stacked as [A, ...] with A = 1 (shared) or N (one per agent)."""
 
@@ -23,12 +26,14 @@ class BatchedActor(object):
         self.non_shared = keys[0].startswith("agents.")
         self.use_rnn = bool(use_rnn)
         self.n_agents = int(n_agents)
-        # fused kernel: how the two GRU matrices are handed over -- True / "bf16x3": three bfloat16 planes (the bfloat16 matrix cores,
-        # six plane products per float32 product, error below a float32 GEMM's own); "f32": float32 in the kernel's streaming order
-        # (f32-input MFMA, 16 x slower per product); False: torch's layout as it is (f32-input MFMA)
-        self.pack_gru = {True: "bf16x3", False: None, None: None}.get(pack_gru, pack_gru)
-        if self.pack_gru not in (None, "bf16x3", "f32"):
-            raise ValueError("pack_gru must be True / 'bf16x3', 'f32' or False")
+        # fused kernel: how the two GRU matrices are handed over -- True / "f16x2": two binary16 planes (three plane products per float32
+        # product on the binary16 matrix cores, error at the level of a float32 GEMM's own roundings; activations above 65 504
+        # saturate); "bf16x3": three bfloat16 planes (six plane products, float32's exponent range, error below a float32 GEMM's
+        # own; 1.2 x the launch time); "f32": float32 in the kernel's streaming order (f32-input MFMA, 16 x slower per product);
+        # False: torch's layout as it is (f32-input MFMA)
+        self.pack_gru = {True: DEFAULT_PACK_GRU, False: None, None: None}.get(pack_gru, pack_gru)
+        if self.pack_gru not in (None, "bf16x3", "f16x2", "f32"):
+            raise ValueError("pack_gru must be True, 'f16x2', 'bf16x3', 'f32' or False")
 
         def stack(name):
             if self.non_shared:
@@ -89,13 +94,16 @@ class BatchedActor(object):
                     if self.pack_gru == "bf16x3":
                         dst = torch.empty(t[k].numel() * 3, dtype=torch.int16, device=t[k].device)   # 6 bytes per weight
                         rc = lib.rg_actor_pack_gru_bf16x3(t[k].data_ptr(), self.w1.shape[0], self.hidden_dim, dst.data_ptr(), stream)
+                    elif self.pack_gru == "f16x2":
+                        dst = torch.empty(t[k].numel() * 2, dtype=torch.int16, device=t[k].device)   # 4 bytes per weight
+                        rc = lib.rg_actor_pack_gru_f16x2(t[k].data_ptr(), self.w1.shape[0], self.hidden_dim, dst.data_ptr(), stream)
                     else:
                         dst = torch.empty_like(t[k])
                         rc = lib.rg_actor_pack_gru(t[k].data_ptr(), self.w1.shape[0], self.hidden_dim, dst.data_ptr(), stream)
                     if rc != 0:
                         raise _lib.RobogymError("rg_actor_pack_gru: " + lib.rg_actor_last_error().decode())
                     t[k] = dst
-                packed = 2 if self.pack_gru == "bf16x3" else 1
+                packed = {"bf16x3": 2, "f16x2": 3}.get(self.pack_gru, 1)
                 # a first launch on ANOTHER stream must not overtake the two pack kernels (forward_fused waits on this once)
                 self._pack_done = torch.cuda.Event()
                 self._pack_done.record(torch.cuda.current_stream(self.w1.device))
@@ -108,11 +116,13 @@ class BatchedActor(object):
                                            self.n_actions, 1 if self.use_rnn else 0, packed)
         return self._ws
 
-    def forward_fused(self, obs, hidden, append_agent_id=True, restart=None, q_out=None, actions_out=None, stream=None):
+    def forward_fused(self, obs, hidden, append_agent_id=True, restart=None, q_out=None, actions_out=None, stream=None,
+                      explore_u=None, epsilon=0.0):
         """One actor step for all E x N agents in one launch (rg_actor_forward: the matrix cores; GRU on bfloat16 planes unless pack_gru says otherwise).
         obs [E,N,D] f32; hidden [E,N,H] f32 updated IN PLACE; restart [E] uint8 (nonzero = start that
         env's hidden state from zero) or None; stream: a torch.cuda.Stream (default: the device's current stream).
-        Returns (q [E,N,A], actions [E,N] int32)."""
+        explore_u [E,N] f32 uniforms in [0, 1) with epsilon > 0: epsilon-greedy actions (rg_actor_forward_explore; the rule is
+        `explore_select` below).  Returns (q [E,N,A], actions [E,N] int32)."""
         import ctypes as C
         from . import _lib
         lib = _lib.load()
@@ -130,12 +140,29 @@ class BatchedActor(object):
                 self._pack_done = None
             else:
                 stream.wait_event(ev)
-        rc = lib.rg_actor_forward(C.byref(ws), E, N, obs.data_ptr(), D, 1 if append_agent_id else 0,
-                                  restart.data_ptr() if restart is not None else None, hidden.data_ptr(),
-                                  q_out.data_ptr(), actions_out.data_ptr(), C.c_void_p(stream.cuda_stream))
+        if explore_u is not None:
+            if explore_u.shape != (E, N) or explore_u.dtype != torch.float32 or not explore_u.is_contiguous():
+                raise ValueError("explore_u must be a contiguous float32 [E, N] tensor")
+            rc = lib.rg_actor_forward_explore(C.byref(ws), E, N, obs.data_ptr(), D, 1 if append_agent_id else 0,
+                                              restart.data_ptr() if restart is not None else None, hidden.data_ptr(),
+                                              q_out.data_ptr(), actions_out.data_ptr(), explore_u.data_ptr(), float(epsilon),
+                                              C.c_void_p(stream.cuda_stream))
+        else:
+            rc = lib.rg_actor_forward(C.byref(ws), E, N, obs.data_ptr(), D, 1 if append_agent_id else 0,
+                                      restart.data_ptr() if restart is not None else None, hidden.data_ptr(),
+                                      q_out.data_ptr(), actions_out.data_ptr(), C.c_void_p(stream.cuda_stream))
         if rc != 0:
             raise _lib.RobogymError("rg_actor_forward: " + lib.rg_actor_last_error().decode())
         return q_out, actions_out
+
+
+def explore_select(greedy, u, epsilon, n_actions, out=None):
+    """The epsilon-greedy rule of rg_actor_forward_explore in torch ops (the composed runner path and the tests use it): with
+    k = int(u * (n_actions / epsilon)) in float32, the action is k where k < n_actions (u < epsilon; k uniform), else greedy."""
+    import numpy as np
+    scale = float(np.float32(n_actions) / np.float32(epsilon))
+    k = (u * torch.tensor(scale, dtype=torch.float32, device=u.device)).to(torch.int32)
+    return torch.where(k < n_actions, k, greedy, out=out)
 
 
 def load_actor(model_file, model_config, n_agents, device="cuda:0"):

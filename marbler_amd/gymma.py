@@ -21,6 +21,7 @@ single-env form with EPyMARL's Python types, for dropping into an unmodified EPy
 import numpy as np
 import torch
 
+from .evaluate import explore_select
 from .vec_env import VecRobotariumEnv
 
 N_ACTIONS = {"PredatorCapturePrey": 5, "Warehouse": 5, "MaterialTransport": 20, "Simple": 5, "ArcticTransport": 5}
@@ -252,8 +253,8 @@ class BatchedRunner(object):
 
     @torch.no_grad()
     def run(self, T):
-        """With the fused env step and the fused actor a time step is TWO launches: the actor reads the previous step's
-        episode-end flags and observation straight from the batch and writes its greedy actions into it; the env step reads
+        """With the fused env step and the fused actor a time step is TWO launches, with exploration too: the actor reads the
+        previous step's episode-end flags and observation straight from the batch and writes its (epsilon-)greedy actions into it; the env step reads
         those actions and writes the next observation (zeros for an env that ended: the reset observation), the summed reward
         and the episode-end flags into the batch (VecRobotariumEnv.step_into).  `state` is a view of `obs` ([E, N * D] of the
         same memory: gymma's state IS the concatenated observations); `episode_start` is filled once per call."""
@@ -267,6 +268,9 @@ class BatchedRunner(object):
         fused = self.actor.fused_supported()
         eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
         direct = fused and v.fused
+        eps = self.epsilon
+        # exploration: ONE uniform per agent and time step, drawn for the whole call in one launch (evaluate.explore_select is the rule)
+        u_all = torch.rand(T, E, N, generator=self.gen, device=dev) if eps > 0.0 else None
         if direct:
             out["state"] = out["obs"].view(T + 1, E, N * D)
             out["obs"][0] = v.get_obs()            # zeros right after a reset, like the reference's reset()
@@ -276,13 +280,9 @@ class BatchedRunner(object):
             for t in range(T):
                 obs = out["obs"][t]
                 restart = self._restart if t == 0 else term_u8[t - 1]
-                greedy = out["actions"][t] if self.epsilon <= 0.0 else None
-                _, greedy = self.actor.forward_fused(obs, self.hidden, append_agent_id=self.obs_agent_id, restart=restart,
-                                                     q_out=self._q, actions_out=greedy)
-                if self.epsilon > 0.0:
-                    explore = torch.rand(E, N, generator=self.gen, device=dev) < self.epsilon
-                    rnd = torch.randint(0, A, (E, N), generator=self.gen, device=dev, dtype=torch.int32)
-                    torch.where(explore, rnd, greedy, out=out["actions"][t])
+                self.actor.forward_fused(obs, self.hidden, append_agent_id=self.obs_agent_id, restart=restart, q_out=self._q,
+                                         actions_out=out["actions"][t], explore_u=None if u_all is None else u_all[t],
+                                         epsilon=eps)
                 rc = env.step_into(out["actions"][t].data_ptr(), out["obs"][t + 1].data_ptr(), out["reward"][t].data_ptr(),
                                    term_u8[t].data_ptr())
                 if rc != 0:
@@ -309,10 +309,8 @@ class BatchedRunner(object):
                 q, h = self.actor.forward(torch.cat([obs, eye], dim=2) if self.obs_agent_id else obs, h_in)
                 self.hidden.copy_(h)
                 greedy = q.argmax(dim=2).to(torch.int32)
-            if self.epsilon > 0.0:
-                explore = torch.rand(E, N, generator=self.gen, device=dev) < self.epsilon
-                rnd = torch.randint(0, A, (E, N), generator=self.gen, device=dev, dtype=torch.int32)
-                torch.where(explore, rnd, greedy, out=out["actions"][t])
+            if eps > 0.0:
+                explore_select(greedy, u_all[t], eps, A, out=out["actions"][t])
             elif not fused:
                 out["actions"][t] = greedy
             reward, ended, _ = v.step(out["actions"][t])

@@ -16,7 +16,10 @@ hipError_t launch_rollout_tpe(const KernelArgs &, hipStream_t) { return hipError
 extern "C" {
 int rg_actor_forward(const rg_actor_weights *, int32_t, int32_t, const float *, int32_t, int32_t, const uint8_t *, float *,
                      float *, int32_t *, void *) { return -100; }
+int rg_actor_forward_explore(const rg_actor_weights *, int32_t, int32_t, const float *, int32_t, int32_t, const uint8_t *,
+                             float *, float *, int32_t *, const float *, float, void *) { return -100; }
 int rg_actor_pack_gru(const float *, int32_t, int32_t, float *, void *) { return -100; }
+int rg_actor_pack_gru_f16x2(const float *, int32_t, int32_t, void *, void *) { return -100; }
 int rg_actor_pack_gru_bf16x3(const float *, int32_t, int32_t, void *, void *) { return -100; }
 const char *rg_actor_last_error(void) { return "host-only sanitizer build: no kernels"; }
 }

@@ -103,6 +103,8 @@ def _draw_actor_case(rng):
     E = int(rng.choice([1, 2, 31, 32, 33, 100, 257]))
     use_rnn = bool(rng.rand() < 0.8)
     pack = [True, "f32", False][int(rng.randint(0, 3))]
+    if rng.rand() < 0.4:     # (drawn after everything else: the cases of earlier rounds keep their shapes)
+        pack = "f16x2" if pack is True else "bf16x3" if pack == "f32" else pack
     return shared, H, E, N, D, A, use_rnn, append, pack
 
 
@@ -181,3 +183,111 @@ def test_greedy_action_is_a_valid_index_on_non_finite_rows(A):
     want = q_ref.argmax(dim=2)
     for a in range(5):                       # the rows made non-finite: exactly torch's answer
         assert torch.equal(act[:, a].long(), want[:, a]), (a, act[:3, a], want[:3, a])
+
+
+@pytest.mark.parametrize("shared,H,A,eps", [(True, 128, 5, 0.25), (False, 64, 20, 0.05), (True, 64, 5, 1.0), (True, 64, 32, 1e-6)])
+def test_epsilon_greedy_selection_inside_the_launch(shared, H, A, eps):
+    """rg_actor_forward_explore: the same launch with EPyMARL's epsilon-greedy selection folded in.  Everything but the actions is
+    identical to the plain launch; the actions equal the rule in torch ops (evaluate.explore_select) applied to the plain launch's
+    greedy actions and the same uniforms; the explored share is epsilon and the explored actions are uniform."""
+    from marbler_amd import _lib
+    from marbler_amd.evaluate import BatchedActor, explore_select
+    dev = "cuda:0"
+    E, N, D = 3000, 4, 9
+    actor = BatchedActor(_random_actor(1 if shared else N, D + N, H, A, True, 8), N, use_rnn=True, device=dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    hidden = torch.rand(E, N, H, generator=g, device=dev) * 2 - 1
+    obs = torch.rand(E, N, D, generator=g, device=dev)
+    u = torch.rand(E, N, generator=g, device=dev)
+    u[0, 0], u[0, 1] = 0.0, float(np.nextafter(np.float32(1.0), np.float32(0.0)))    # the ends of the range
+    h0, h1 = hidden.clone(), hidden.clone()
+    q0, greedy = actor.forward_fused(obs, h0)
+    q1, act = actor.forward_fused(obs, h1, explore_u=u, epsilon=eps)
+    torch.cuda.synchronize()
+    assert torch.equal(q0, q1) and torch.equal(h0, h1)
+    want = explore_select(greedy, u, eps, A)
+    assert torch.equal(act, want)
+    assert int(act.min()) >= 0 and int(act.max()) < A
+    assert int(act[0, 0]) == 0 and (eps == 1.0 or int(act[0, 1]) == int(greedy[0, 1]))
+    explored = u < eps
+    if eps >= 0.05:
+        share = float(explored.float().mean())
+        assert abs(share - eps) < 4 * (eps * (1 - eps) / (E * N)) ** 0.5 + 1e-3
+        counts = torch.bincount(act[explored].long(), minlength=A).float()
+        expect = float(explored.sum()) / A
+        assert float(((counts - expect) ** 2 / expect).sum()) < 3 * A + 20      # chi-square, loose
+    # what is not explored is the greedy action (the boundary u ~ epsilon is decided by the float32 product: skip one ulp of it)
+    clear = (u >= eps * 1.0001) | (u <= eps * 0.9999)
+    assert torch.equal(act[clear & ~explored], greedy[clear & ~explored])
+    assert bool((act[clear & explored] == (u[clear & explored] / eps * A).floor().clamp(max=A - 1).int()).float().mean() > 0.999)
+    # argument checks
+    with pytest.raises(_lib.RobogymError):
+        actor.forward_fused(obs, h1, explore_u=u, epsilon=0.0)
+    with pytest.raises(ValueError):
+        actor.forward_fused(obs, h1, explore_u=u[:, :2], epsilon=eps)
+
+
+@pytest.mark.parametrize("shared,H,E,N,D,A", [(True, 128, 300, 5, 16, 5), (False, 64, 130, 5, 16, 5), (True, 64, 77, 4, 9, 20),
+                                                (False, 128, 33, 3, 30, 7)])
+def test_two_binary16_planes_match_torch_and_the_three_plane_form(shared, H, E, N, D, A):
+    """gru_packed = 3 (rg_actor_pack_gru_f16x2): three plane products per float32 product.  Against torch's float32 evaluation to the
+    same 1e-5 as every other form over a few recurrent steps, and against the three-bfloat16-plane form (error far below float32's
+    own) to 3e-6 -- a float32 GEMM's own roundings are of that size."""
+    from marbler_amd.evaluate import BatchedActor
+    dev = "cuda:0"
+    sd = _random_actor(1 if shared else N, D + N, H, A, True, seed=H + E)
+    fast, fine = (BatchedActor(sd, N, use_rnn=True, device=dev, pack_gru=p) for p in ("f16x2", "bf16x3"))
+    g = torch.Generator(device=dev).manual_seed(2)
+    hidden = torch.rand(E, N, H, generator=g, device=dev) * 2 - 1
+    h_fine, h_ref = hidden.clone(), hidden.clone()
+    eye = torch.eye(N, device=dev).unsqueeze(0).expand(E, N, N)
+    worst = 0.0
+    for step in range(4):
+        obs = torch.rand(E, N, D, generator=g, device=dev) * 3 - 1.5
+        q_ref, h_ref = fast.forward(torch.cat([obs, eye], dim=2), h_ref)
+        q, act = fast.forward_fused(obs, hidden)
+        q3, act3 = fine.forward_fused(obs, h_fine)
+        torch.cuda.synchronize()
+        assert float((q - q_ref).abs().max()) < 1e-5 and float((hidden - h_ref).abs().max()) < 1e-5, step
+        worst = max(worst, float((q - q3).abs().max()), float((hidden - h_fine).abs().max()))
+        top2 = q_ref.topk(2, dim=2).values
+        clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+        assert torch.equal(act[clear], act3[clear])
+    assert worst < 3e-6, worst
+
+
+def test_two_binary16_planes_on_values_outside_binary16s_normal_range():
+    """Activations and weights below 2^-14 (binary16's smallest normal number) travel in the scaled low plane alone; the result must
+    not lose them: a network whose recurrent weights and hidden state are mostly tiny, against the three-plane form."""
+    from marbler_amd.evaluate import BatchedActor
+    dev = "cuda:0"
+    E, N, D, H, A = 64, 4, 12, 128, 5
+    sd = _random_actor(1, D + N, H, A, True, seed=21)
+    g0 = torch.Generator().manual_seed(4)
+    for k in ("rnn.weight_hh", "rnn.weight_ih"):
+        w = sd[k]
+        tiny = torch.rand(w.shape, generator=g0) < 0.5
+        scale = 10.0 ** (-4 - 4 * torch.rand(w.shape, generator=g0))       # 1e-4 ... 1e-8
+        sd[k] = torch.where(tiny, w * scale, w)
+    fast, fine = (BatchedActor(sd, N, use_rnn=True, device=dev, pack_gru=p) for p in ("f16x2", "bf16x3"))
+    g = torch.Generator(device=dev).manual_seed(6)
+    for amp in (1.0, 3e-5, 1e-7):
+        hidden = (torch.rand(E, N, H, generator=g, device=dev) * 2 - 1) * amp
+        # large recurrent products on purpose: tiny h x weights scaled UP would show a lost hi plane
+        obs = torch.rand(E, N, D, generator=g, device=dev) * amp
+        h2 = hidden.clone()
+        q, _ = fast.forward_fused(obs, hidden)
+        q3, _ = fine.forward_fused(obs, h2)
+        torch.cuda.synchronize()
+        assert float((q - q3).abs().max()) < 2e-6 and float((hidden - h2).abs().max()) < 2e-6, amp
+    # the lost-plane check proper: gh = h W_hh with h ~ 3e-5 and W_hh ~ 3e3 (products of order 1 from operands below 2^-14)
+    sd2 = dict(sd)
+    sd2["rnn.weight_hh"] = sd["rnn.weight_hh"].sign() * 3e3 * torch.rand(sd["rnn.weight_hh"].shape, generator=g0)
+    fast, fine = (BatchedActor(sd2, N, use_rnn=True, device=dev, pack_gru=p) for p in ("f16x2", "bf16x3"))
+    hidden = (torch.rand(E, N, H, generator=g, device=dev) * 2 - 1) * 3e-5
+    obs = torch.rand(E, N, D, generator=g, device=dev)
+    h2 = hidden.clone()
+    q, _ = fast.forward_fused(obs, hidden)
+    q3, _ = fine.forward_fused(obs, h2)
+    torch.cuda.synchronize()
+    assert float((q - q3).abs().max()) < 1e-5 and float((hidden - h2).abs().max()) < 1e-5

@@ -115,3 +115,34 @@ def test_random_barrier_family_is_bit_exact(i, oracle_lib, monkeypatch):
         _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E, require_done=False)
     except AssertionError as exc:
         raise AssertionError(f"case {i}: {scenario} {ov} E={E} kernel={kernel}: {exc}") from exc
+
+
+def draw_interior_point(rng):
+    """draw_config restricted to what `barrier_solver: cvxopt` admits (n_agents <= 8), with the certificate family and cvxopt's own
+    options drawn too (tight tolerances: many iterations; a small iteration cap: the cap binds)."""
+    while True:
+        scenario, ov, n_act, E, kernel = draw_barrier_family(rng) if rng.rand() < 0.5 else draw_config(rng)
+        n = int(ov.get("n_agents", 4))
+        if n <= 8:
+            break
+    ov["barrier_solver"] = "cvxopt"
+    if rng.rand() < 0.3:
+        ov["cvxopt_reltol"] = float(rng.choice([1e-1, 1e-3, 1e-5]))
+        ov["cvxopt_feastol"] = float(rng.choice([1e-1, 1e-2, 1e-4]))
+    if rng.rand() < 0.2:
+        ov["cvxopt_maxiters"] = int(rng.choice([0, 1, 4, 12]))
+    return scenario, ov, n_act, min(E, 129), kernel
+
+
+IPM_CASES = [draw_interior_point(np.random.RandomState(7000 + i)) for i in range(64)]
+
+
+@pytest.mark.parametrize("i", range(len(IPM_CASES)))
+def test_random_interior_point_configuration_is_bit_exact(i, oracle_lib, monkeypatch):
+    scenario, ov, n_act, E, kernel = IPM_CASES[i]
+    monkeypatch.setenv("RG_STEP_KERNEL", kernel)
+    steps = 30 if scenario != "MaterialTransport" else 16
+    try:
+        _rollout_bit_exact(scenario, ov, n_act, steps, oracle_lib, E, require_done=False)
+    except AssertionError as exc:
+        raise AssertionError(f"case {i}: {scenario} {ov} E={E} kernel={kernel}: {exc}") from exc

@@ -203,7 +203,14 @@ def _worker(rank, world, port, q):
     rs = torch.arange(off, off + cnt, dtype=torch.float32) * 0.5
     cs = torch.arange(off, off + cnt, dtype=torch.int32) + BIG     # above 2^24: a float32 round trip would lose the low bits
     ss = cs * 10
-    out = rgdist.gather_episode_stats(rs, cs, ss, dst=0)
+    out = rgdist.gather_episode_stats(rs, cs, ss, dst=0)                    # sizes exchanged by the call
+    out2 = rgdist.gather_episode_stats(rs, cs, ss, dst=0, total_envs=9)     # sizes from the shard rule: one collective
+    assert (out is None) == (out2 is None) and (out is None or all(torch.equal(a, b) for a, b in zip(out, out2)))
+    try:
+        rgdist.gather_episode_stats(rs, cs, ss, dst=0, total_envs=11)
+        raise AssertionError("a shard that disagrees with total_envs must be refused")
+    except ValueError:
+        pass
     q.put((r, params_to_bytes(p), None if out is None else [t.tolist() for t in out]))
     import torch.distributed as dist
     dist.barrier()

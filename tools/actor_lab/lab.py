@@ -48,6 +48,9 @@ def bind(path):
     if hasattr(lib, "rg_actor_pack_gru_bf16x3"):
         lib.rg_actor_pack_gru_bf16x3.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         lib.rg_actor_pack_gru_bf16x3.restype = C.c_int
+    if hasattr(lib, "rg_actor_pack_gru_f16x2"):
+        lib.rg_actor_pack_gru_f16x2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        lib.rg_actor_pack_gru_f16x2.restype = C.c_int
     lib.rg_actor_last_error.restype = C.c_char_p
     return lib
 
@@ -105,7 +108,12 @@ if __name__ == "__main__":
         for (E, N, D, H, A, shared, rnn) in ((4096, 4, 16, 128, 5, True, True), (4096, 4, 16, 64, 5, True, True), (1024, 4, 16, 128, 5, True, True),
                                              (8192, 4, 16, 128, 5, True, True), (4096, 5, 16, 128, 5, False, True), (4096, 4, 9, 128, 20, True, False),
                                              (300, 5, 16, 128, 5, True, True)):
-            for pack in ((True, "f32") if (hasattr(lib, "rg_actor_pack_gru_bf16x3") and rnn) else (True,)):
+            packs = (True,)
+            if rnn and hasattr(lib, "rg_actor_pack_gru_f16x2"):
+                packs = ("f16x2", "bf16x3") if "--all" not in sys.argv else ("f16x2", "bf16x3", "f32")
+            elif rnn and hasattr(lib, "rg_actor_pack_gru_bf16x3"):
+                packs = (True, "f32")
+            for pack in packs:
                 rows.append(case(lib, E, N, D, H, A, shared, rnn, pack=pack))
                 print(name, json.dumps(rows[-1]), flush=True)
         if hasattr(lib, "rg_actor_occupancy"):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a wave of the fused actor kernel spends its time: a -DRG_ACTOR_STAMPS build of csrc/actor_mfma.hip alone (phase stamps
 from s_memtime written behind q; python tools/actor_lab/lab.py build v2s="-DRG_ACTOR_STAMPS").
-    python tools/actor_stamps.py [--lib tools/actor_lab/build/actor_v2s.so]"""
+    python tools/actor_stamps.py [--lib tools/actor_lab/build/actor_v2s.so] [--pack f16x2|bf16x3|f32]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,11 +22,14 @@ lib.rg_actor_pack_gru.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int3
 lib.rg_actor_last_error.restype = ctypes.c_char_p
 if hasattr(lib, "rg_actor_pack_gru_bf16x3"):
     lib.rg_actor_pack_gru_bf16x3.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+if hasattr(lib, "rg_actor_pack_gru_f16x2"):
+    lib.rg_actor_pack_gru_f16x2.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+PACK = sys.argv[sys.argv.index("--pack") + 1] if "--pack" in sys.argv else True
 _lib._lib = lib     # the actor-only diagnostic build stands in for the library
 print(LIB)
 N, D = 4, 16
 for E, H in ((4096, 128), (4096, 64), (1024, 128)):
-    actor = BatchedActor(_random_actor(1, D + N, H, 5, True, 3), N, device="cuda:0")
+    actor = BatchedActor(_random_actor(1, D + N, H, 5, True, 3), N, device="cuda:0", pack_gru=PACK)
     obs = torch.rand(E, N, D, device="cuda:0")
     hidden = torch.zeros(E, N, H, device="cuda:0")
     waves = (E * N // 32) * (H // 32)
