@@ -137,6 +137,13 @@ __device__ __forceinline__ void split1(float x, _Float16 &hi, _Float16 &lo) {
     lo = static_cast<_Float16>((x - static_cast<float>(hi)) * F16_LO_SCALE);
 }
 
+// a workgroup barrier that orders LDS traffic only: global stores in flight stay in flight
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int H, int SPLIT>   // SPLIT: the GRU's products on 1: three bfloat16 planes (gru_packed == 2), 2: two binary16 planes (gru_packed == 3)
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256 registers (VGPR + AGPR): two tiles per CU, one's serial phases under the other's MFMAs
 __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
@@ -176,17 +183,23 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     const float *Whh = a.w.whh + static_cast<size_t>(set) * 3 * H * H, *Bhh = a.w.bhh + static_cast<size_t>(set) * 3 * H;
     const float *W2 = a.w.w2 + static_cast<size_t>(set) * A * H, *B2 = a.w.b2 + static_cast<size_t>(set) * A;
 
-    // ---- the old hidden state: every thread's share of the tile is requested first and lands in LDS behind fc1
+    // ---- the old hidden state: every thread's share of the tile is requested at the head and lands in LDS behind fc1.
+    // ORDER of the head's requests (the vector-memory counter retires in order, a wait can only leave the YOUNGEST loads in
+    // flight): restart flag, fc1's staged operands, THEN the hidden state -- so that the wait in front of the staging stores
+    // leaves the hidden state's trip to HBM in flight.  (Until round 5 the hidden state was asked for first, and the restart
+    // flag's `s_waitcnt vmcnt(0)` -- the flag goes into LDS ahead of the staging loads -- waited for all of it: the staging loads
+    // were not even issued before the slowest load of the launch had come back.)
     constexpr int HV = (TM * (H / 4)) / NTHREADS;  // float4 per thread (4)
     float4 hv[HV];
+    auto request_hidden = [&] {
 #pragma unroll
-    for (int m = 0; m < HV; ++m) {
-        const int idx = tid + NTHREADS * m, i = idx / (H / 4), k4 = idx % (H / 4);
-        // (the loads do not wait for the restart flag: one memory round trip, the flag is applied to what comes back)
-        const int r = row_ok(i) ? row_of(i) : 0;
-        hv[m] = *reinterpret_cast<const float4 *>(a.hidden + static_cast<size_t>(r) * H + 4 * k4);
-    }
-    RG_HSTAMP(2);  // (head) hidden-state loads issued
+        for (int m = 0; m < HV; ++m) {
+            const int idx = tid + NTHREADS * m, i = idx / (H / 4), k4 = idx % (H / 4);
+            // (the loads do not wait for the restart flag: one memory round trip, the flag is applied to what comes back)
+            const int r = row_ok(i) ? row_of(i) : 0;
+            hv[m] = *reinterpret_cast<const float4 *>(a.hidden + static_cast<size_t>(r) * H + 4 * k4);
+        }
+    };
     auto zero16 = [] {
         floatx16 z;
 #pragma unroll
@@ -227,26 +240,38 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         const bool ok = row_ok(srow);
         const int r = ok ? row_of(srow) : 0;
         const int env = shared ? r / N : base + srow, agent = shared ? r - env * N : set;
-        const bool live = ok && !(a.restart && a.restart[ok ? env : 0] != 0);
-        // a restarted env starts from the reference's reset(): zero hidden state, zero observation (PredatorCapturePrey.py:136)
-        if (part == 0) live_s[srow] = live ? 1 : 0;
+        int restarted = a.restart ? a.restart[ok ? env : 0] : 0;
+        const float *xrow = a.obs + static_cast<size_t>(r) * a.D;
+        const int id_k = (ok && a.append_agent_id) ? a.D + agent : -1;   // where this row's one-hot agent id sits
+        float xv[32 / TPRX];
+        u32x4 wv[4];
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W1 + static_cast<size_t>(cb) * 32 * I);   // rows 32 cb .. 32 cb + 31: 8 I float4
         if (staged) {
-            const float *xrow = a.obs + static_cast<size_t>(r) * a.D;
-            const int id_k = (ok && a.append_agent_id) ? a.D + agent : -1;   // where this row's one-hot agent id sits
-            float xv[32 / TPRX];
-            u32x4 wv[4];
+            // (unconditional loads from clamped places, what lies beyond the row is replaced where it is used: a predicated load is
+            // a branch around one instruction, twelve of them here)
 #pragma unroll
             for (int m = 0; m < 32 / TPRX; ++m) {
                 const int k = part + TPRX * m;
-                xv[m] = (ok && k < a.D) ? xrow[k] : 0.0f;   // (not gated by the restart flag: that would be a second round trip)
+                xv[m] = xrow[k < a.D ? k : 0];   // (not gated by the restart flag: that would be a second round trip)
             }
-            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(W1 + static_cast<size_t>(cb) * 32 * I);   // rows 32 cb .. 32 cb + 31: 8 I float4
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int f4 = lane + 64 * m;
-                wv[m] = f4 < 8 * I ? wsrc[f4] : u32x4{0u, 0u, 0u, 0u};
+                wv[m] = wsrc[f4 < 8 * I ? f4 : 0];
             }
-            RG_HSTAMP(3);  // (head) staging loads requested
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RG_HSTAMP(3);  // (head) staging loads requested
+        request_hidden();
+        __builtin_amdgcn_sched_barrier(0);
+        RG_HSTAMP(2);  // (head) hidden-state loads issued
+        // a restarted env starts from the reference's reset(): zero hidden state, zero observation (PredatorCapturePrey.py:136)
+        // (the flag is kept opaque up to here: left to itself the compiler compares it to zero where it is loaded, and the wait for
+        // the load stands in front of every other request of the head)
+        asm volatile("" : "+v"(restarted));
+        const bool live = ok && restarted == 0;
+        if (part == 0) live_s[srow] = live ? 1 : 0;
+        if (staged) {
 #pragma unroll
             for (int m = 0; m < 32 / TPRX; ++m) {
                 const int k = part + TPRX * m;
@@ -308,6 +333,28 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     RG_HSTAMP(4);  // (head) fc1's products and its bias have arrived
 #endif
     __syncthreads();   // every wave is done with the staged operands: their place becomes Y and the old hidden state
+    // SPLIT == 2: the head of the GRU's weight stream and its biases are requested HERE, ahead of fc1's epilogue (its conversions,
+    // LDS stores and barrier), not behind it: the stream's first trip to L2 runs under the epilogue.
+    // The stream: [cb][ks][gate][plane][lane][8] binary16, groups (ks, gate, matrix) of two 16-byte operands and three MFMAs; PD
+    // groups in flight ahead, held in place by the fences (see the three-plane form).  (3 and 4 in flight measured no faster.)
+    constexpr int KS = H / 16, NG = KS * 6, PD = 2, RING = PD + 1;
+    u32x4 wq[RING][2];
+    float br = 0.0f, bz = 0.0f, bin = 0.0f, bhn = 0.0f;
+    const uint16_t *Pih = reinterpret_cast<const uint16_t *>(a.w.wih) + static_cast<size_t>(set) * 3 * H * H * 2;
+    const uint16_t *Phh = reinterpret_cast<const uint16_t *>(a.w.whh) + static_cast<size_t>(set) * 3 * H * H * 2;
+    auto load_w = [&](int t, u32x4 (&wl)[2]) {
+        const int ks = t / 6, g = (t % 6) >> 1, hh = t & 1;
+        const uint16_t *src = (hh ? Phh : Pih) + ((static_cast<size_t>((cb * KS + ks) * 3 + g) * 2) * 64 + lane) * 8;
+        wl[0] = *reinterpret_cast<const u32x4 *>(src);
+        wl[1] = *reinterpret_cast<const u32x4 *>(src + 64 * 8);
+    };
+    if constexpr (SPLIT == 2) {
+        const int j = cb * 32 + col;
+        br = Bih[j] + Bhh[j], bz = Bih[H + j] + Bhh[H + j], bin = Bih[2 * H + j], bhn = Bhh[2 * H + j];
+#pragma unroll
+        for (int t = 0; t < PD; ++t) load_w(t, wq[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (SPLIT == 2) {   // the GRU's A operands as binary16 planes, split here once (not by every wave at every k step)
 #pragma unroll
         for (int r_ = 0; r_ < 16; ++r_) {
@@ -366,32 +413,18 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     if (a.w.use_rnn && SPLIT == 2) {   // two binary16 planes: three products per float32 product
         if constexpr (SPLIT == 2) {
             const int j = cb * 32 + col;
-            const float br = Bih[j] + Bhh[j], bz = Bih[H + j] + Bhh[H + j], bin = Bih[2 * H + j], bhn = Bhh[2 * H + j];
-            __builtin_amdgcn_sched_barrier(0);
             // accumulators: 0 = r, 1 = z (input and recurrent products meet in one), 2 = the input half of n, 3 = its recurrent
             // half (r multiplies that one); am: hi hi, ac: the cross products at scale 2^11
+            // (the hi hi accumulators START at the biases: the gate arithmetic -- VALU-bound with both tiles of a SIMD in it -- is four
+            // additions per element shorter)
             floatx16 am[4], ac[4];
+            const float bias4[4] = {br, bz, bin, bhn};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                am[g] = zero16();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) am[g][r] = bias4[g];
                 ac[g] = zero16();
             }
-            // the stream: [cb][ks][gate][plane][lane][8] binary16, groups (ks, gate, matrix) of two 16-byte operands and three
-            // MFMAs; PD groups in flight ahead, held in place by the fences (see the three-plane form)
-            constexpr int KS = H / 16, NG = KS * 6;
-            const size_t set_off = static_cast<size_t>(set) * 3 * H * H * 2;
-            const uint16_t *Pih = reinterpret_cast<const uint16_t *>(a.w.wih) + set_off, *Phh = reinterpret_cast<const uint16_t *>(a.w.whh) + set_off;
-            auto load_w = [&](int t, u32x4 (&wl)[2]) {
-                const int ks = t / 6, g = (t % 6) >> 1, hh = t & 1;
-                const uint16_t *src = (hh ? Phh : Pih) + ((static_cast<size_t>((cb * KS + ks) * 3 + g) * 2) * 64 + lane) * 8;
-                wl[0] = *reinterpret_cast<const u32x4 *>(src);
-                wl[1] = *reinterpret_cast<const u32x4 *>(src + 64 * 8);
-            };
-            constexpr int PD = 2, RING = PD + 1;   // (3 and 4 in flight measured no faster: 20.4 / 20.9 / 20.5 us)
-            u32x4 wq[RING][2];
-#pragma unroll
-            for (int t = 0; t < PD; ++t) load_w(t, wq[t]);
-            __builtin_amdgcn_sched_barrier(0);
             f16x8 yh, yl, hh_, hl_;
 #pragma unroll
             for (int t = 0; t < NG; ++t) {
@@ -422,10 +455,10 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             request_fc2();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float rg_ = sigmoidf_(__builtin_fmaf(ac[0][r], F16_LO_UNSCALE, am[0][r]) + br);
-                const float zg = sigmoidf_(__builtin_fmaf(ac[1][r], F16_LO_UNSCALE, am[1][r]) + bz);
-                const float ni = __builtin_fmaf(ac[2][r], F16_LO_UNSCALE, am[2][r]) + bin;
-                const float nh = __builtin_fmaf(ac[3][r], F16_LO_UNSCALE, am[3][r]) + bhn;
+                const float rg_ = sigmoidf_(__builtin_fmaf(ac[0][r], F16_LO_UNSCALE, am[0][r]));
+                const float zg = sigmoidf_(__builtin_fmaf(ac[1][r], F16_LO_UNSCALE, am[1][r]));
+                const float ni = __builtin_fmaf(ac[2][r], F16_LO_UNSCALE, am[2][r]);
+                const float nh = __builtin_fmaf(ac[3][r], F16_LO_UNSCALE, am[3][r]);
                 const float ng = tanhf_(ni + rg_ * nh);
                 hn[r] = (1.0f - zg) * ng + zg * Hs[swz<H>(crow(r), j)];
             }
@@ -587,7 +620,19 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
     RG_ASTAMP(3);  // gates
 #endif
 #endif
-    __syncthreads();  // every read of the old hidden state and of Y is done
+    // The new hidden state goes out to memory NOW, from the accumulator layout (per register: two rows x 128 contiguous bytes per
+    // wave), and drains under fc2 and the arg-max.  The barriers from here on order LDS only (lds_barrier): __syncthreads would
+    // wait for these stores at every one of them -- which is why, until round 5, they were issued at the very end, where all 512
+    // tiles' 8.4 MB met the memory system in one burst with nothing left to run under it.
+    {
+        const int j = cb * 32 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = crow(r);
+            if (row_ok(i)) a.hidden[static_cast<size_t>(row_of(i)) * H + j] = hn[r];
+        }
+    }
+    lds_barrier();  // every read of the old hidden state and of Y is done
     {
         const int j = cb * 32 + col;
 #pragma unroll
@@ -596,11 +641,10 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             Hs[swz<H>(i, j)] = hn[r];
         }
     }
-    __syncthreads();
+    lds_barrier();
 #ifndef RG_ACTOR_STAMPS_FC1
     RG_ASTAMP(4);  // new hidden state in LDS
 #endif
-    // (the new hidden state's copy to memory goes out at the very end: a barrier here would wait for the stores)
 
     // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one 32 x 32 tile).  The K range is split over the tile's wavefronts --
     // 32 k values = 16 MFMAs each instead of H / 2 on one wavefront while the others wait -- and the partial tiles meet in LDS.
@@ -614,7 +658,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Y[cb * (TM * 32) + crow(r) * 32 + col] = acc[r];  // Y is free again: NW partial tiles, row-major
     }
-    __syncthreads();
+    lds_barrier();
 #ifndef RG_ACTOR_STAMPS_FC1
     RG_ASTAMP(5);  // fc2 partial products
 #endif
@@ -658,14 +702,6 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 if (static_cast<unsigned>(k) < static_cast<unsigned>(A)) arg = k;
             }
             a.actions[r] = arg;
-        }
-    }
-    {
-        const int j = cb * 32 + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = crow(r);
-            if (row_ok(i)) a.hidden[static_cast<size_t>(row_of(i)) * H + j] = hn[r];
         }
     }
 #ifdef RG_ACTOR_STAMPS
