@@ -459,8 +459,10 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 const float zg = sigmoidf_(__builtin_fmaf(ac[1][r], F16_LO_UNSCALE, am[1][r]));
                 const float ni = __builtin_fmaf(ac[2][r], F16_LO_UNSCALE, am[2][r]);
                 const float nh = __builtin_fmaf(ac[3][r], F16_LO_UNSCALE, am[3][r]);
-                const float ng = tanhf_(ni + rg_ * nh);
-                hn[r] = (1.0f - zg) * ng + zg * Hs[swz<H>(crow(r), j)];
+                // (fused forms written out: this file is compiled with contraction off, and the gates are VALU-bound)
+                const float e2 = __builtin_amdgcn_exp2f(__builtin_fmaf(rg_, nh, ni) * 2.8853900817779268f);   // exp(2 a) = 2^(2 a log2 e)
+                const float ng = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e2), 1.0f);                // tanh a
+                hn[r] = __builtin_fmaf(zg, Hs[swz<H>(crow(r), j)] - ng, ng);                                    // (1 - z) n + z h
             }
         }
     } else if (a.w.use_rnn) {  // torch.nn.GRUCell: gates r, z, n in that order
