@@ -338,6 +338,43 @@ def rollout_leg(env, dev, n_act, seed, launches=16):
             "agent_steps_per_s": env.E * env.N / (ms * 1e-3), "hbm_achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
 
 
+def host_boundary_leg(env, dev, n_act, steps=200):
+    """Side measurement (not `value`): the same step with a HOST consumer on both sides -- the rate a trainer sees that keeps its
+    actions and transition data in host memory (the reference's own shape: NumPy in, NumPy out).  Per step: the action batch
+    [E, N] int32 goes up from pinned memory, rg_step runs, observations / rewards / done flags come down to pinned memory, and
+    the host waits for them (it needs them to choose the next actions).  The C ABI itself takes device pointers; `value` is
+    measured with everything resident in HBM.  PCIe-inclusive by construction."""
+    import numpy as np
+    import torch
+    E, N = env.E, env.N
+    rng = np.random.RandomState(3)
+    act_host = torch.from_numpy(rng.randint(0, n_act, size=(8, E, N)).astype(np.int32)).pin_memory()
+    act_dev = torch.empty(E, N, dtype=torch.int32, device=dev)
+    obs_h = torch.empty_like(env.obs, device="cpu").pin_memory()
+    rew_h = torch.empty_like(env.reward, device="cpu").pin_memory()
+    done_h = torch.empty_like(env.done_u8, device="cpu").pin_memory()
+    nbytes = act_dev.numel() * 4 + obs_h.numel() * 4 + rew_h.numel() * 4 + done_h.numel()
+
+    def one(i):
+        act_dev.copy_(act_host[i % 8], non_blocking=True)
+        env.step_raw(act_dev.data_ptr())
+        obs_h.copy_(env.obs, non_blocking=True)
+        rew_h.copy_(env.reward, non_blocking=True)
+        done_h.copy_(env.done_u8, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+
+    env._sync_stream()
+    for i in range(20):
+        one(i)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"what": "rg_step with host-resident actions and outputs (pinned buffers, one synchronisation per step)", "steps": steps,
+            "ms_per_step": ms, "agent_steps_per_s": E * N / (ms * 1e-3), "bytes_over_pcie_per_step": nbytes,
+            "pcie_GBs": nbytes / (ms * 1e-3) / 1e9}
+
+
 def graph_leg(env, dev, ptrs, K, regions=40):
     """The timed region's K rg_step launches recorded once into a hipGraph and replayed: the same kernels, no host call
     per step.  A 20-step region launched step by step is exposed to the host's jitter (1 region in 8 ran 10-20 % slow on
@@ -828,6 +865,7 @@ def main():
             if not args.no_graph:
                 out["graph_replay"] = graph_leg(env, dev, ptrs, min(K, 100))
             out["rollout"] = rollout_leg(env, dev, n_act, 777)
+            out["host_boundary"] = host_boundary_leg(env, dev, n_act)
             out["saturated"] = saturated_leg(dev, overrides)
             out["actor"] = actor_leg(dev)
             out["interior_point_mode"] = ipm_leg(dev, overrides)
