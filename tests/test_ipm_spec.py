@@ -112,3 +112,38 @@ def test_interior_point_iterate_stops_strictly_inside(oracle_lib):
         n += 1
         closer += float(np.abs(ip[0]).sum() < np.abs(ex[0]).sum())           # smaller forward speeds towards the crowd
     assert n > 60 and closer / n > 0.6, (n, closer)
+
+
+@pytest.mark.parametrize("N", [2, 4, 5, 8])
+def test_tight_tolerances_bring_the_iterate_to_the_projection(N, oracle_lib):
+    """Two algorithms, one QP: the restated interior-point iteration run to tight tolerances (1e-10 on the gap, 1e-8 on the
+    residuals, 100 iterations allowed) must end at the exact projection the Hildreth sweeps compute -- the optimum cvxopt's
+    iterate approaches; at rps' reltol 1e-2 it stops well short of it (the test above).  A gap of 1e-10 bounds the distance to the
+    optimum of this strongly convex QP by its square root, ~1e-5 (x 20 through the unicycle map's 1 / projection distance on the
+    angular velocity).  The cvxopt operation order factors the KKT matrix by a Cholesky step that can fail on the ill-conditioned
+    systems of the last iterations (cvxopt then returns the iterate it has: status 'unknown'); the float spec's LDL^T does not."""
+    rng = np.random.RandomState(100 + N)
+    scenario = "PredatorCapturePrey" if N <= 5 else "Warehouse"
+    ov = {"predator": N - N // 2, "capture": N // 2, "n_agents": N} if scenario == "PredatorCapturePrey" else {"n_agents": N}
+    cfg = load_config(scenario, overrides=ov)
+    tight = {"cvxopt_abstol": 1e-10, "cvxopt_reltol": 1e-10, "cvxopt_feastol": 1e-8, "cvxopt_maxiters": 100}
+    worst = active = compared = agree = 0
+    dists = []
+    for t in range(60):
+        P, G = _draw(rng, N, close=True)
+        if t % 2:
+            G = np.repeat(P[:2].mean(axis=1, keepdims=True), N, axis=1)
+        ex, sweeps = oracle_lib.controller(scenario, dict(cfg, qp_max_sweeps=20000, qp_rtol=1e-13), P, G, np.float64)
+        if sweeps >= 20000:
+            continue
+        loose, _ = oracle_lib.controller(scenario, dict(cfg, barrier_solver="cvxopt"), P, G, np.float64)
+        spec, _ = oracle_lib.controller(scenario, dict(cfg, barrier_solver="ipm_spec", **tight), P, G, np.float64)
+        cvx, _ = oracle_lib.controller(scenario, dict(cfg, barrier_solver="cvxopt", **tight), P, G, np.float64)
+        dists.append(float(np.abs(spec - ex).max()))
+        worst = max(worst, dists[-1])
+        agree += float(np.abs(cvx - ex).max() < 5e-4)
+        active += float(np.abs(loose - ex).max() > 1e-3)
+        compared += 1
+    assert worst < 5e-5 and float(np.median(dists)) < 1e-7, (worst, float(np.median(dists)))   # measured: 1.8e-5 / 1e-9
+    assert compared >= 55 and agree >= 0.95 * compared, (compared, agree)
+    assert active >= 8, active          # rps' own tolerance leaves differences an order of magnitude larger on the same inputs
