@@ -6,20 +6,26 @@
 // tile of 32 agent rows and carries it through the whole network, wavefront w computing the 32 hidden columns
 // [32 w, 32 w + 32) of every layer:
 //     X [32 x I]  --fc1-->  Y [32 x H]  --GRU (6 gate tiles per 32 hidden columns)-->  h' [32 x H]  --fc2--> q [32 x A]
-// * The GRU -- 96 % of the arithmetic -- has two forms.  gru_packed == 2 (rg_actor_pack_gru_bf16x3, the default of
-//   marbler_amd/evaluate.py): every float32 value is carried as THREE bfloat16 planes (see split8 below) and a float32
-//   product becomes six plane products on v_mfma_f32_32x32x16_bf16 (32 cycles for K = 16), 6/16 of the float32 MFMA time, with
-//   an error below a float32 dot product's own roundings.  gru_packed == 0 / 1: f32-input MFMA (v_mfma_f32_32x32x2_f32, 64
-//   cycles for K = 2), exact float32 products.  Round 4 at 4096 x 4 rows, hidden 128: 25.2 us per launch against 47-50 us
-//   (132 TFLOP/s of the network's arithmetic = 84 % of the dense float32 MFMA peak).
+// * The GRU -- 96 % of the arithmetic -- has three forms.  gru_packed == 3 (rg_actor_pack_gru_f16x2, the default of
+//   marbler_amd/evaluate.py since round 5): every float32 value is carried as TWO binary16 planes (hi, 2^11 lo) and a float32
+//   product becomes three plane products on v_mfma_f32_32x32x16_f16, the cross terms in a second accumulator; the activations are
+//   split where they are produced, into plane images in LDS (see "two binary16 planes" below).  gru_packed == 2
+//   (rg_actor_pack_gru_bf16x3, round 4): THREE bfloat16 planes (split8 below), six plane products on v_mfma_f32_32x32x16_bf16
+//   (32 cycles for K = 16), float32's exponent range, an error below a float32 dot product's own roundings.  gru_packed == 0 / 1:
+//   f32-input MFMA (v_mfma_f32_32x32x2_f32, 64 cycles for K = 2), exact float32 products.  At 4096 x 4 rows, hidden 128:
+//   19-20 / 24-26 / 44-50 us per launch.
 // * A operands (activations) are read from LDS; B operands of the GRU (weights) stream from L2 in the order a pack routine
 //   wrote them (1 KB per load instruction), a ring of groups ahead of the MFMAs, held in place by scheduling fences.  fc1's
 //   small ragged operands are fetched once per tile, coalesced, and staged in LDS (inputs up to 32 wide; wider ones are read
 //   as they lie by a ROLLED loop: unrolled, the layer was ~600 instructions of cold code at the head of every launch).
-// * Two [32][H] LDS images with an XOR swizzle instead of padding, and 256 registers per lane (amdgpu_waves_per_eu): TWO tiles
-//   per CU, one wave of each per SIMD.  (Rounds 1-3 ran one tile per CU -- 352 registers per lane; the 42.5 KB of padded LDS
-//   they also used was NOT the limit, although hipOccupancyMaxActiveBlocksPerMultiprocessor, which reckons with 64 KB of LDS
-//   per CU, says so: the same kernel with its LDS padded to 52 KB still runs two tiles per CU at the same speed.)
+// * Two [32][H] float32 LDS images with an XOR swizzle instead of padding (a third, of binary16 planes, in the two-plane form:
+//   48 KB per tile at hidden 128), and 256 registers per lane (amdgpu_waves_per_eu): TWO tiles per CU, one wave of each per SIMD.
+//   (Rounds 1-3 ran one tile per CU -- 352 registers per lane; LDS was never the limit: hipOccupancyMaxActiveBlocksPerMultiprocessor
+//   reckons with 64 KB of LDS per CU, the hardware has 160.)
+// * Memory traffic is ordered by hand: the head requests the restart flag, fc1's staged operands and then the hidden state (the
+//   vector-memory counter retires in order: the wait in front of the staging stores leaves the hidden state in flight); the GRU's
+//   first weight groups go out ahead of fc1's epilogue; the new hidden state is stored right after the gates and drains under fc2
+//   and the arg-max, whose barriers order LDS only (lds_barrier).
 // * Layer outputs come out of the MFMA with the column on the lane and 16 rows in registers (C/D map: col = lane & 31,
 //   row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)); the gate arithmetic is elementwise in that layout and one LDS write turns it
 //   into the next layer's A image.  fc2's K range is split over the tile's wavefronts, the partial tiles meet in LDS, and all
