@@ -67,6 +67,65 @@ def test_create_rejects_bad_parameters_without_touching_a_gpu():
     assert not lib.rg_create(ctypes.byref(base()), 0, 0, 0, None) and b"num_envs" in lib.rg_last_error()
 
 
+def test_actor_entry_points_reject_bad_arguments_without_touching_a_gpu():
+    """rg_actor_forward / rg_actor_forward_explore / the pack routines check their arguments before anything is launched: every
+    refusal names its reason (rg_actor_last_error).  The pointers are host buffers that are never dereferenced."""
+    from marbler_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p).value
+
+    def weights(**kw):
+        d = dict(w1=ptr, b1=ptr, wih=ptr, bih=ptr, whh=ptr, bhh=ptr, w2=ptr, b2=ptr, n_sets=1, input_dim=20, hidden_dim=128,
+                 n_actions=5, use_rnn=1, gru_packed=3)
+        d.update(kw)
+        return _lib.RgActorWeights(d["w1"], d["b1"], d["wih"], d["bih"], d["whh"], d["bhh"], d["w2"], d["b2"], d["n_sets"],
+                                   d["input_dim"], d["hidden_dim"], d["n_actions"], d["use_rnn"], d["gru_packed"])
+
+    def fwd(w, E=8, N=4, D=16, append=1, obs=ptr, hidden=ptr, actions=ptr, u=None, eps=0.0):
+        if u is None:
+            return lib.rg_actor_forward(ctypes.byref(w), E, N, obs, D, append, None, hidden, None, actions, None)
+        return lib.rg_actor_forward_explore(ctypes.byref(w), E, N, obs, D, append, None, hidden, None, actions, u, eps, None)
+
+    for call, word in ((lambda: fwd(weights(), obs=None), b"NULL"), (lambda: fwd(weights(w2=None)), b"NULL"),
+                       (lambda: fwd(weights(whh=None)), b"whh"), (lambda: fwd(weights(hidden_dim=96)), b"hidden_dim"),
+                       (lambda: fwd(weights(n_actions=33)), b"n_actions"), (lambda: fwd(weights(gru_packed=4)), b"gru_packed"),
+                       (lambda: fwd(weights(n_sets=3)), b"n_sets"), (lambda: fwd(weights(), E=0), b"num_envs"),
+                       (lambda: fwd(weights(), D=17), b"input_dim"), (lambda: fwd(weights(input_dim=80), D=76), b"above 64"),
+                       (lambda: fwd(weights(), u=ptr, eps=0.0), b"epsilon"), (lambda: fwd(weights(), u=ptr, eps=1.5), b"epsilon"),
+                       (lambda: fwd(weights(), u=ptr, eps=0.1, actions=None), b"actions array")):
+        rc = call()
+        assert rc != 0 and word in lib.rg_actor_last_error(), (rc, word, lib.rg_actor_last_error())
+    for pack in (lib.rg_actor_pack_gru_f16x2, lib.rg_actor_pack_gru_bf16x3, lib.rg_actor_pack_gru):
+        assert pack(None, 1, 128, ptr, None) != 0 and pack(ptr, 0, 128, ptr, None) != 0 and pack(ptr, 1, 96, ptr, None) != 0
+    assert lib.rg_actor_pack_gru_f16x2(ptr, 1, 128, ptr + 4, None) != 0 and b"aligned" in lib.rg_actor_last_error()
+
+
+def test_epsilon_greedy_rule_in_torch_ops():
+    """evaluate.explore_select, the rule rg_actor_forward_explore applies inside the launch: k = int(u * (A / eps)) in float32 is the
+    action where k < A, the greedy action elsewhere.  Exploration share = eps, explored actions uniform, ends of the range."""
+    import numpy as np
+    import torch
+    from marbler_amd.evaluate import explore_select
+    g = torch.Generator().manual_seed(1)
+    for A, eps in ((5, 0.25), (20, 0.05), (32, 1.0), (5, 1e-6)):
+        u = torch.rand(20000, 4, generator=g)
+        u[0, 0], u[0, 1] = 0.0, float(np.nextafter(np.float32(1.0), np.float32(0.0)))
+        greedy = torch.full((20000, 4), A - 1, dtype=torch.int32)
+        act = explore_select(greedy, u, eps, A)
+        assert act.dtype == torch.int32 and int(act.min()) >= 0 and int(act.max()) < A
+        assert int(act[0, 0]) == 0 and (eps == 1.0 or int(act[0, 1]) == A - 1)
+        explored = u < eps
+        clear = (u >= eps * 1.0001) | (u <= eps * 0.9999)
+        assert torch.equal(act[clear & ~explored], greedy[clear & ~explored])
+        if eps >= 0.05:
+            counts = torch.bincount(act[explored].long(), minlength=A).float()
+            expect = float(explored.sum()) / A
+            assert float(((counts - expect) ** 2 / expect).sum()) < 3 * A + 20
+        out = torch.empty_like(greedy)
+        assert explore_select(greedy, u, eps, A, out=out) is out and torch.equal(out, act)
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
