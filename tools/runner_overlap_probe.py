@@ -33,6 +33,25 @@ class Half:
         torch.cuda.synchronize()
         v.env.set_stream(stream)
 
+        # pointer-level form of the same two calls: no tensor views per step
+        import ctypes as C
+        from marbler_amd import _lib
+        self.lib = _lib.load()
+        self.ws = self.actor._weights_struct()
+        self.actor.forward_fused(self.obs[0], self.hidden, restart=self.restart, q_out=self.q, actions_out=self.actions[0], stream=stream)
+        torch.cuda.synchronize()
+        self.sp = C.c_void_p(stream.cuda_stream)
+        N, D = v.n_agents, v.obs_size
+        self.args = [(self.obs[t].data_ptr(), (self.restart if t == 0 else self.term[t - 1]).data_ptr(), self.actions[t].data_ptr(),
+                      self.obs[t + 1].data_ptr(), self.reward[t].data_ptr(), self.term[t].data_ptr()) for t in range(T)]
+        self.n, self.N, self.D, self.hp, self.qp = n, N, D, self.hidden.data_ptr(), self.q.data_ptr()
+        self.wsref = C.byref(self.ws)
+
+    def step_ptr(self, t):
+        o, r, a, o1, rw, tm = self.args[t]
+        self.lib.rg_actor_forward(self.wsref, self.n, self.N, o, self.D, 1, r, self.hp, self.qp, a, self.sp)
+        self.v.env.step_into(a, o1, rw, tm)
+
     def step(self, t):
         restart = self.restart if t == 0 else self.term[t - 1]
         self.actor.forward_fused(self.obs[t], self.hidden, restart=restart, q_out=self.q, actions_out=self.actions[t], stream=self.stream)
@@ -40,22 +59,25 @@ class Half:
         assert rc == 0
 
 
-def run(halves):
+def run(halves, ptr=False):
+    steps = [h.step_ptr if ptr else h.step for h in halves]
     for t in range(20):
-        for h in halves:
-            h.step(t)
+        for f in steps:
+            f(t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(T):
-        for h in halves:
-            h.step(t)
+        for f in steps:
+            f(t)
+    host = (time.perf_counter() - t0) / T * 1e6
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / T * 1e6
+    return (time.perf_counter() - t0) / T * 1e6, host
 
 
 s0 = torch.cuda.current_stream()
-one = run([Half(E, 3, s0)])
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-two = run([Half(E // 2, 3, sa), Half(E // 2, 4, sb)])
-same = run([Half(E // 2, 3, s0), Half(E // 2, 4, s0)])
-print(f"E {E} hidden {H}: one batch {one:.1f} us per time step; two halves on two streams {two:.1f}; two halves on one stream {same:.1f}")
+for ptr in (False, True):
+    one = run([Half(E, 3, s0)], ptr)
+    two = run([Half(E // 2, 3, sa), Half(E // 2, 4, sb)], ptr)
+    print(f"E {E} hidden {H} {'pointer-level calls' if ptr else 'tensor-level calls'}: one batch {one[0]:.1f} us per time step (host loop {one[1]:.1f}); "
+          f"two halves on two streams {two[0]:.1f} (host loop {two[1]:.1f})", flush=True)
