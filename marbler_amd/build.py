@@ -14,8 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librobogym_hip.so")
-SOURCES = ["robogym_kernels.hip", "robogym_rollout_group.hip", "robogym_tpe.hip", "robogym_rollout_tpe.hip", "robogym_capi.hip",
-           "actor_mfma.hip"]
+SOURCES = ["robogym_kernels.hip", "robogym_rollout_group.hip", "robogym_kernels_ipm.hip", "robogym_rollout_group_ipm.hip",
+           "robogym_tpe.hip", "robogym_rollout_tpe.hip", "robogym_capi.hip", "actor_mfma.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("sim_math.h", "kernel_args.h", "device_common.h", "step_group.h", "step_tpe.h", "step_tpe_ipm.h", "ipm_qp.h", os.path.join("probes", "diag.h"))
                                            if os.path.exists(os.path.join(CSRC, h))] + \
           [os.path.join(HERE, "..", "include", "robogym.h")]
@@ -43,8 +43,15 @@ ARCH = "gfx950"
 # tests/test_kernel_resources.py scans every kernel of the shipped library for it (tools/isa_scan.py exec_prologue).
 # The N = 7, 8 instantiations were never dispatched and are no longer built.
 GROUP_SLP = ["-mllvm", "-slp-threshold=-60"]
+# The interior-point mode's lane-group kernels (their own translation units) are long chains of binary64 arithmetic with
+# independent strands beside them: the max-ILP scheduling strategy interleaves the strands (round 5, whole-library A/B on one box:
+# interior-point mode 4096 x 5 141.8 -> 134.3 us, Warehouse 4096 x 8 607 -> 548, MaterialTransport 2048 x 6 unchanged; exact mode
+# 12.70 -> 12.74, 32 768 envs 27.1 -> 29.0: NOT for the other files).  The one-lane-per-env interior-point kernels stay with the
+# default strategy: under max-ILP the N = 5 one shows the exec-prologue shape isa_scan looks for.
+IPM_SCHED = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 FILE_FLAGS = {"robogym_tpe.hip": ["-fno-slp-vectorize"], "robogym_rollout_tpe.hip": ["-fno-slp-vectorize"],
-              "robogym_kernels.hip": GROUP_SLP, "robogym_rollout_group.hip": GROUP_SLP}
+              "robogym_kernels.hip": GROUP_SLP, "robogym_rollout_group.hip": GROUP_SLP,
+              "robogym_kernels_ipm.hip": GROUP_SLP + IPM_SCHED, "robogym_rollout_group_ipm.hip": GROUP_SLP + IPM_SCHED}
 BASE_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 STAMP = LIB + ".flags"
 

@@ -128,5 +128,9 @@ hipError_t launch_step_tpe(const KernelArgs &a, hipStream_t stream);
 // rg_rollout: num_steps env steps per launch (robogym_rollout_group.hip, robogym_rollout_tpe.hip)
 hipError_t launch_rollout(const KernelArgs &a, hipStream_t stream);
 hipError_t launch_rollout_tpe(const KernelArgs &a, hipStream_t stream);
+// the lane-group kernels of the interior-point mode (robogym_kernels_ipm.hip, robogym_rollout_group_ipm.hip); a.envs_per_wave and
+// the grid as launch_step_scn computed them
+hipError_t launch_step_ipm(const KernelArgs &a, int grid, hipStream_t stream);
+hipError_t launch_rollout_ipm(const KernelArgs &a, int grid, hipStream_t stream);
 
 }  // namespace rg

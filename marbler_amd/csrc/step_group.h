@@ -1369,19 +1369,8 @@ static hipError_t launch_step_scn(const KernelArgs &a_in, hipStream_t stream) {
     }
     const int grid = (a.E + epw - 1) / epw;
     if constexpr (!OBS_ONLY) {
-        if (a.p.qp_mode == RG_QP_CVXOPT) {  // (rg_create admits n_agents <= 8 in this mode)
-            constexpr int Q = RG_QP_CVXOPT;
-            if constexpr (!ROLLOUT) {
-                if (a.io.elapsed) {
-                    if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, false, true, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
-                    else hipLaunchKernelGGL((step_kernel<SCN, 8, false, 0, false, true, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
-                    return hipGetLastError();
-                }
-            }
-            if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, ROLLOUT, false, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
-            else hipLaunchKernelGGL((step_kernel<SCN, 8, false, 0, ROLLOUT, false, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
-            return hipGetLastError();
-        }
+        // the interior-point mode's kernels live in their own translation units (robogym_kernels_ipm.hip, robogym_rollout_group_ipm.hip)
+        if (a.p.qp_mode == RG_QP_CVXOPT) return ROLLOUT ? launch_rollout_ipm(a, grid, stream) : launch_step_ipm(a, grid, stream);
     }
     if constexpr (!OBS_ONLY && !ROLLOUT) {
         if (a.io.elapsed) {  // gymma block: its own instantiations (generic agent count)
@@ -1416,19 +1405,8 @@ static hipError_t launch_step_group(const KernelArgs &a, hipStream_t stream) {
             return launch_step_scn<RG_SCN_SIMPLE, OBS_ONLY, ROLLOUT>(a, stream);
         case RG_SCN_ARCTIC_TRANSPORT:
             if constexpr (!OBS_ONLY) {
-                if (a.p.qp_mode == RG_QP_CVXOPT) {
-                    constexpr int Q = RG_QP_CVXOPT;
-                    if constexpr (!ROLLOUT) {
-                        if (a.io.elapsed) {
-                            hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false, 0, false, true, Q>), dim3((a.E + 15) / 16),
-                                               dim3(WAVE), 0, stream, a);
-                            return hipGetLastError();
-                        }
-                    }
-                    hipLaunchKernelGGL((step_kernel<RG_SCN_ARCTIC_TRANSPORT, 4, false, 0, ROLLOUT, false, Q>), dim3((a.E + 15) / 16),
-                                       dim3(WAVE), 0, stream, a);
-                    return hipGetLastError();
-                }
+                if (a.p.qp_mode == RG_QP_CVXOPT)
+                    return ROLLOUT ? launch_rollout_ipm(a, (a.E + 15) / 16, stream) : launch_step_ipm(a, (a.E + 15) / 16, stream);
             }
             if constexpr (!OBS_ONLY && !ROLLOUT) {
                 if (a.io.elapsed) {
@@ -1442,6 +1420,35 @@ static hipError_t launch_step_group(const KernelArgs &a, hipStream_t stream) {
             return hipGetLastError();
         default:
             return hipErrorInvalidValue;
+    }
+}
+
+// QPM = RG_QP_CVXOPT: launch dispatch of the interior-point mode's kernels (rg_create admits n_agents <= 8 in this mode).  Called
+// from the translation units that instantiate them, compiled with their own scheduler flag (build.py FILE_FLAGS).
+template <int SCN, bool ROLLOUT>
+static hipError_t launch_ipm_scn(const KernelArgs &a, int grid, hipStream_t stream) {
+    constexpr int Q = RG_QP_CVXOPT;
+    const int gw = SCN == RG_SCN_ARCTIC_TRANSPORT ? 4 : group_width(a.p.n_agents);
+    if constexpr (!ROLLOUT) {
+        if (a.io.elapsed) {   // gymma block
+            if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, false, true, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+            else if constexpr (SCN != RG_SCN_ARCTIC_TRANSPORT) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 0, false, true, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
+    if (gw == 4) hipLaunchKernelGGL((step_kernel<SCN, 4, false, 0, ROLLOUT, false, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+    else if constexpr (SCN != RG_SCN_ARCTIC_TRANSPORT) hipLaunchKernelGGL((step_kernel<SCN, 8, false, 0, ROLLOUT, false, Q>), dim3(grid), dim3(WAVE), 0, stream, a);
+    return hipGetLastError();
+}
+template <bool ROLLOUT>
+static hipError_t launch_ipm_group(const KernelArgs &a, int grid, hipStream_t stream) {
+    switch (a.p.scenario) {
+        case RG_SCN_PREDATOR_CAPTURE_PREY: return launch_ipm_scn<RG_SCN_PREDATOR_CAPTURE_PREY, ROLLOUT>(a, grid, stream);
+        case RG_SCN_WAREHOUSE: return launch_ipm_scn<RG_SCN_WAREHOUSE, ROLLOUT>(a, grid, stream);
+        case RG_SCN_MATERIAL_TRANSPORT: return launch_ipm_scn<RG_SCN_MATERIAL_TRANSPORT, ROLLOUT>(a, grid, stream);
+        case RG_SCN_SIMPLE: return launch_ipm_scn<RG_SCN_SIMPLE, ROLLOUT>(a, grid, stream);
+        case RG_SCN_ARCTIC_TRANSPORT: return launch_ipm_scn<RG_SCN_ARCTIC_TRANSPORT, ROLLOUT>(a, grid, stream);
+        default: return hipErrorInvalidValue;
     }
 }
 
