@@ -82,7 +82,8 @@ __device__ __forceinline__ void split8(const float4 &lo4, const float4 &hi4, bf1
 // products on v_mfma_f32_32x32x16_f16 (the same 32 cycles for K = 16 as the bfloat16 instruction), the two cross products into
 // a second accumulator that joins the first with one multiply-add in the gate arithmetic.  Measured on 2048 x 128 x 384 random
 // operands against the exact product: max 3.9e-7, rms 5.6e-8 -- a float32 GEMM of the same operands: 9.5e-7 / 7.5e-8.
-// Range: binary16's.  Activations are the hidden state (in [-1, 1]) and fc1's ReLU output; |x| > 65504 saturates (never inf).
+// Range: binary16's.  Activations are the hidden state (in [-1, 1]) and fc1's ReLU output; |x| > 65504 saturates (f16_saturate:
+// never inf; the same for a weight).
 // Below 2^-14 hi is a binary16 DENORMAL (spacing 2^-24) and lo' the 11 bits after it: conversions and the matrix cores take
 // denormal operands as they are on gfx950 (round 5: with them flushed -- s_setreg MODE.FP_DENORM -- a hidden state of 3e-5 kept 11
 // bits in all, and products against large weights were off by 2e-4; tests/test_gpu_actor.py holds the case).
@@ -111,6 +112,8 @@ struct ActorArgs {
 // gate nonlinearities on the hardware exponential (v_exp_f32, ~1 ulp on 2^t): absolute error ~1e-7 on
 // outputs in [0, 1] / [-1, 1], far inside the 1e-5 parity bar, at a tenth of libm's instruction count
 // (v_rcp_f32 is within 1 ulp; `1.0f / x` would be the ten-instruction correctly rounded division, 48 times per lane and tile)
+// torch.relu: a NaN stays a NaN (v_max_f32 would return the 0)
+__device__ __forceinline__ float relu_(float x) { return x < 0.0f ? 0.0f : x; }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
@@ -138,7 +141,12 @@ __device__ __forceinline__ int swz4(int i, int k4) { return i * H + ((k4 ^ (i & 
 template <int H>
 __device__ __forceinline__ int swz8(int i, int b8) { return i * H + ((b8 ^ (i & 7)) << 3); }
 // one value -> its two planes, rounded to nearest (the activations are split where they are PRODUCED, once per tile)
+// (beyond binary16's largest finite value the conversion would round to infinity and the low plane to NaN: the value saturates
+// instead -- comparisons, so that a NaN stays a NaN)
+constexpr float F16_MAX = 65504.0f;
+__device__ __forceinline__ float f16_saturate(float x) { return x > F16_MAX ? F16_MAX : x < -F16_MAX ? -F16_MAX : x; }
 __device__ __forceinline__ void split1(float x, _Float16 &hi, _Float16 &lo) {
+    x = f16_saturate(x);
     hi = static_cast<_Float16>(x);
     lo = static_cast<_Float16>((x - static_cast<float>(hi)) * F16_LO_SCALE);
 }
@@ -365,14 +373,14 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
 #pragma unroll
         for (int r_ = 0; r_ < 16; ++r_) {
             _Float16 hi, lo;
-            split1(fmaxf(acc[r_] + b1, 0.0f), hi, lo);
+            split1(relu_(acc[r_] + b1), hi, lo);
             const int at = swz8<H>(crow(r_), n >> 3) + (n & 7);
             Yp[at] = hi;
             Yp[TM * H + at] = lo;
         }
     } else {
 #pragma unroll
-        for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = fmaxf(acc[r_] + b1, 0.0f);
+        for (int r_ = 0; r_ < 16; ++r_) Y[swz<H>(crow(r_), n)] = relu_(acc[r_] + b1);
     }
 #pragma unroll
     for (int m = 0; m < HV; ++m) {
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 acc = mfma4(acc, *reinterpret_cast<const float4 *>(&Y[swz4<H>(col, (half * (H / 2) + 4 * q) >> 2)]), wrow[q]);
             request_fc2();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hn[r] = fmaxf(acc[r] + b, 0.0f);
+            for (int r = 0; r < 16; ++r) hn[r] = relu_(acc[r] + b);
         }
     }
 #ifdef RG_ACTOR_STAMPS
@@ -790,7 +798,7 @@ __global__ void pack_gru_f16x2_kernel(const float *src, uint16_t *dst, int n_set
         const int s = static_cast<int>(r);
         const int half = lane >> 5, col = lane & 31;
         const int row = g * H + cb * 32 + col, k = ks * 16 + half * 8 + e;
-        const float w = src[(static_cast<size_t>(s) * 3 * H + row) * H + k];
+        const float w = f16_saturate(src[(static_cast<size_t>(s) * 3 * H + row) * H + k]);
         const _Float16 hi = static_cast<_Float16>(w);
         const float rest = (w - static_cast<float>(hi)) * F16_LO_SCALE;
         const _Float16 lo = static_cast<_Float16>(rest);

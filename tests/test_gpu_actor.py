@@ -291,3 +291,34 @@ def test_two_binary16_planes_on_values_outside_binary16s_normal_range():
     q3, _ = fine.forward_fused(obs, h2)
     torch.cuda.synchronize()
     assert float((q - q3).abs().max()) < 1e-5 and float((hidden - h2).abs().max()) < 1e-5
+
+
+def test_two_binary16_planes_saturate_beyond_binary16s_range_and_keep_nans():
+    """An activation beyond 65 504 (here: a hidden unit of fc1 whose bias is 1e5, its weights zero) would convert to infinity and its
+    low plane to NaN; the two-plane form saturates it instead -- the outputs are finite and bit-identical to those of the same
+    network with that bias AT 65 504 -- and a NaN observation still gives NaN action values, in its own rows only."""
+    from marbler_amd.evaluate import BatchedActor
+    dev = "cuda:0"
+    E, N, D, H, A = 40, 4, 12, 128, 5
+    outs = []
+    for bias in (1e5, 65504.0):
+        sd = _random_actor(1, D + N, H, A, True, seed=31)
+        sd["fc1.weight"][3] = 0.0
+        sd["fc1.bias"][3] = bias
+        sd["rnn.weight_ih"][:, 3] *= 1e-3          # (keeps the gates' pre-activations in a range where the outputs still move)
+        actor = BatchedActor(sd, N, use_rnn=True, device=dev, pack_gru="f16x2")
+        g = torch.Generator(device=dev).manual_seed(8)
+        hidden = torch.rand(E, N, H, generator=g, device=dev) * 2 - 1
+        obs = torch.rand(E, N, D, generator=g, device=dev)
+        q, act = actor.forward_fused(obs, hidden)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(q).all()) and bool(torch.isfinite(hidden).all()), bias
+        outs.append((q.clone(), hidden.clone(), act.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    obs[5, 2, 0] = float("nan")
+    hidden = torch.rand(E, N, H, generator=g, device=dev) * 2 - 1
+    q, act = actor.forward_fused(obs, hidden)
+    torch.cuda.synchronize()
+    bad = torch.isnan(q).any(dim=2)
+    assert bool(bad[5, 2]) and int(bad.sum()) == 1
+    assert int(act.min()) >= 0 and int(act.max()) < A
