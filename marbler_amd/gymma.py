@@ -260,6 +260,8 @@ class BatchedRunner(object):
         same memory: gymma's state IS the concatenated observations); `episode_start` is filled once per call."""
         v, env, dev = self.venv, self.venv.env, self.venv.env.device
         E, N, D, A = v.E, v.n_agents, v.obs_size, v.n_actions
+        if int(T) < 1:
+            raise ValueError("run(T) collects T >= 1 time steps")
         out = {"obs": torch.empty(T + 1, E, N, D, device=dev),
                "avail_actions": torch.ones(T + 1, E, N, A, dtype=torch.int32, device=dev),
                "actions": torch.empty(T, E, N, dtype=torch.int32, device=dev),
