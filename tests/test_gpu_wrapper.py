@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 
 MSG = {0: None, 1: "collision", 2: "boundary", 3: "collision_boundary"}
 FILES = ["pcp_n5", "warehouse_n8", "mt_n6", "simple_n4_default", "arctic_default", "viol_PredatorCapturePrey_both",
-         "viol_Warehouse_late_boundary", "viol_ArcticTransport_collision"]
+         "viol_Warehouse_late_boundary", "viol_ArcticTransport_collision",
+         # the same facade with `barrier_solver: cvxopt` in the YAML: the reference's vectors over the restated cvxopt iterate
+         "ipm_pcp_n5", "ipm_warehouse_n8", "ipm_mt_n6", "ipm_arctic_default", "ipm_viol_PredatorCapturePrey_both"]
 
 
 @pytest.mark.parametrize("name", FILES)
@@ -180,7 +182,7 @@ def test_batched_runner_in_place_path_equals_the_composed_one(key, ov, limit, ep
         assert torch.allclose(x["reward"], y["reward"], rtol=0, atol=2e-6), "reward"
 
 
-@pytest.mark.parametrize("name", ["pcp_n5", "warehouse_n8", "mt_n6", "viol_PredatorCapturePrey_collision"])
+@pytest.mark.parametrize("name", ["pcp_n5", "warehouse_n8", "mt_n6", "viol_PredatorCapturePrey_collision", "ipm_pcp_n5", "ipm_warehouse_n8"])
 def test_gymma_env_reduces_the_reference_vectors_like_epymarl(name):
     """GymmaEnv (EPyMARL's gymma contract: float(sum(reward_n)), all(done_n), padded per-agent observations,
     state = their concatenation) fed the reference's own states and actions must return the reductions of the
