@@ -13,6 +13,8 @@ state = zeros; an episode ends with done[0]) on the C oracle at the scenario's s
 
   * float32            : sim_spec_v0 in binary32 = the HIP kernels, bit for bit (tests/test_gpu_*.py);
   * float64_exact      : the same spec in float64 (barrier QP = exact projection);
+  * float32_cvxopt_restated : the float32 tier with the barrier QP as the restated cvxopt iterate (`barrier_solver: cvxopt`,
+    ipm_spec_v0) = the HIP kernels' interior-point mode, bit for bit (round 5);
   * float64_cvxopt_restated : float64 with the barrier QP as a restated cvxopt interior-point iterate at the reference's
                          tolerances (oracle_core.h barrier_qp_ipm) -- a STUDY of the unpinned solver layer, not a pin.
 
@@ -39,7 +41,10 @@ for p in (ROOT, os.path.join(ROOT, "tests"), HERE):
         sys.path.insert(0, p)
 
 SEED = 2024
-VARIANTS = {"float32": (np.float32, {}), "float64_exact": (np.float64, {}), "float64_cvxopt_restated": (np.float64, {"qp_solver": "cvxopt_restated"})}
+VARIANTS = {"float32": (np.float32, {}), "float64_exact": (np.float64, {}), "float64_cvxopt_restated": (np.float64, {"qp_solver": "cvxopt_restated"}),
+            # round 5: the float32 tier with `barrier_solver: cvxopt` = the HIP kernels' interior-point mode, bit for bit
+            "float32_cvxopt_restated": (np.float32, {"barrier_solver": "cvxopt"})}
+REPLAY_VARIANTS = {"float32": "", "float32_cvxopt_restated": "ipm__"}   # variant -> key prefix in zoo_eval_replay.npz
 REPLAY_ROWS = ("PredatorCapturePrey/qmix", "Warehouse/vdn", "MaterialTransport/mappo")
 REPLAY_ENVS = 64
 
@@ -171,11 +176,11 @@ def main():
             row = {"agent": mcfg.get("agent"), "hidden_dim": mcfg["hidden_dim"], "use_rnn": mcfg.get("use_rnn", True), "obs_agent_id": mcfg.get("obs_agent_id", True),
                    "algorithm": mcfg.get("name"), "variants": {}}
             for vname, (dtype, extra) in VARIANTS.items():
-                rec = REPLAY_ENVS if (vname == "float32" and name in REPLAY_ROWS) else 0
+                rec = REPLAY_ENVS if (vname in REPLAY_VARIANTS and name in REPLAY_ROWS) else 0
                 summary, replay = evaluate(scenario, dict(cfg, **extra), p, model, mcfg, ns, args.episodes, dtype, record=rec)
                 row["variants"][vname] = summary
                 if replay:
-                    replays[name] = replay
+                    replays[(REPLAY_VARIANTS[vname], name)] = replay
             out["models"][name] = row
             v = row["variants"]
             print(name, {k: (round(v[k]["return_mean"], 3), round(v[k]["steps_mean"], 2), v[k]["ended_by"]["collision"], v[k]["ended_by"]["boundary"]) for k in v}, flush=True)
@@ -183,9 +188,9 @@ def main():
         with open(os.path.join(HERE, "ZOO_EVAL.json"), "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
             f.write("\n")
-        flat = {"rows": np.array(sorted(replays)), "seed": np.int64(SEED)}
-        for name, rp in replays.items():
-            key = name.replace("/", "__")
+        flat = {"rows": np.array(sorted({name for _, name in replays})), "seed": np.int64(SEED)}
+        for (prefix, name), rp in replays.items():
+            key = prefix + name.replace("/", "__")
             for k, v in rp.items():
                 flat[f"{key}__{k}"] = v
         np.savez_compressed(os.path.join(HERE, "zoo_eval_replay.npz"), **flat)

@@ -1,4 +1,4 @@
-"""Three rows of tests/golden/ZOO_EVAL.json on the GPU, bit for bit.
+"""Three rows of tests/golden/ZOO_EVAL.json on the GPU, bit for bit, in both barrier-QP modes.
 
 ZOO_EVAL.json records what the reference's own trained policies (scenarios/*/models/*.th, "the final models we evaluated
 in the paper", robotarium_gym/README.md:63) score on this engine, per tier (tests/golden/make_zoo_eval.py).  The checkpoints
@@ -24,16 +24,20 @@ def _rows():
     return [str(r) for r in np.load(REPLAY)["rows"]]
 
 
+@pytest.mark.parametrize("solver", ["exact", "cvxopt"])
 @pytest.mark.parametrize("row", _rows())
-def test_recorded_policy_rollout_reproduces_the_committed_episode_statistics(row):
+def test_recorded_policy_rollout_reproduces_the_committed_episode_statistics(row, solver):
+    """solver = cvxopt: the `float32_cvxopt_restated` rows of the record (round 5) -- the same policies on the interior-point mode,
+    their own recorded actions (keys `ipm__...`)."""
     import torch
     from marbler_amd import VecRobotariumEnv
     z = np.load(REPLAY)
-    key = row.replace("/", "__")
+    key = ("ipm__" if solver == "cvxopt" else "") + row.replace("/", "__")
     acts = z[f"{key}__actions"]                       # [T, E, N] int8
     T, E, N = acts.shape
     scenario = row.split("/")[0]
-    env = VecRobotariumEnv(scenario, E, seed=int(z["seed"]), auto_reset=False)
+    env = VecRobotariumEnv(scenario, E, seed=int(z["seed"]), auto_reset=False,
+                           overrides={"barrier_solver": "cvxopt"} if solver == "cvxopt" else None)
     env.reset()
     assert env.N == N
     ret, dist = np.zeros(E, np.float64), np.zeros((E, N), np.float64)
@@ -65,6 +69,7 @@ def test_replay_rows_are_rows_of_the_record():
     rec = json.load(open(os.path.join(GOLDEN_DIR, "ZOO_EVAL.json")))
     z = np.load(REPLAY)
     for row in rows:
-        f32 = rec["models"][row]["variants"]["float32"]
-        r = z[f"{row.replace('/', '__')}__return"]
-        assert abs(r.mean() - f32["return_mean"]) <= 4 * f32["return_std"] / np.sqrt(len(r)) + 1e-9, row
+        for variant, prefix in (("float32", ""), ("float32_cvxopt_restated", "ipm__")):
+            f32 = rec["models"][row]["variants"][variant]
+            r = z[f"{prefix}{row.replace('/', '__')}__return"]
+            assert abs(r.mean() - f32["return_mean"]) <= 4 * f32["return_std"] / np.sqrt(len(r)) + 1e-9, (row, variant)

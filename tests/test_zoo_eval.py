@@ -17,8 +17,13 @@ def test_record_covers_the_model_zoo():
     rec = json.load(open(REC))
     assert len(rec["models"]) == 22 and rec["episodes_per_row"] >= 200
     for name, row in rec["models"].items():
-        assert set(row["variants"]) == {"float32", "float64_exact", "float64_cvxopt_restated"}, name
+        assert set(row["variants"]) == {"float32", "float64_exact", "float64_cvxopt_restated", "float32_cvxopt_restated"}, name
         f32, f64 = row["variants"]["float32"], row["variants"]["float64_exact"]
+        # round 5: the interior-point mode's float32 tier (= the kernels with barrier_solver: cvxopt) against the float64 restatement
+        i32, i64 = row["variants"]["float32_cvxopt_restated"], row["variants"]["float64_cvxopt_restated"]
+        se_i = np.hypot(i32["return_std"], i64["return_std"]) / np.sqrt(i32["episodes"])
+        assert abs(i32["return_mean"] - i64["return_mean"]) <= 5 * se_i + 1e-9, (name, i32["return_mean"], i64["return_mean"])
+        assert abs(i32["steps_mean"] - i64["steps_mean"]) <= 5 * np.hypot(i32["steps_std"], i64["steps_std"]) / np.sqrt(i32["episodes"]) + 1e-9, name
         for v in row["variants"].values():
             assert v["episodes"] == rec["episodes_per_row"] and sum(v["ended_by"].values()) == v["episodes"], name
         # the float32 tier (= the kernels) against the same spec in float64, same initial states, same policy: trajectories part
@@ -36,11 +41,11 @@ def test_replay_through_the_float32_oracle_reproduces_the_recorded_statistics(or
     per-episode statistics of the npz, exactly (what the GPU tier then asks of the kernels)."""
     from marbler_amd.params import load_config, make_params
     z = np.load(REPLAY)
-    for row in [str(r) for r in z["rows"]]:
-        key, scenario = row.replace("/", "__"), row.split("/")[0]
+    for row, prefix, ov in [(str(r), pre, ov) for r in z["rows"] for pre, ov in (("", {}), ("ipm__", {"barrier_solver": "cvxopt"}))]:
+        key, scenario = prefix + row.replace("/", "__"), row.split("/")[0]
         acts = z[f"{key}__actions"]
         T, E, N = acts.shape
-        cfg = load_config(scenario)
+        cfg = load_config(scenario, overrides=ov or None)
         p = make_params(scenario, cfg)
         orc = oracle_lib.OracleVecEnv(scenario, cfg, E, dtype=np.float32)
         rp = oracle_reset_params(oracle_lib, p)
