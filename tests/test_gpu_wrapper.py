@@ -148,7 +148,9 @@ def test_batched_runner_collects_transitions():
     ("robotarium_gym:PredatorCapturePrey-v0", {}, 25, 0.25),
     ("robotarium_gym:Warehouse-v0", {}, 30, 0.25),                 # rows of 18 floats: not whole 16-byte units
     ("robotarium_gym:MaterialTransport-v0", {}, 12, 0.25),         # 9-float rows, 20 actions
-    ("robotarium_gym:PredatorCapturePrey-v0", {"predator": 3, "capture": 2, "n_agents": 5}, 25, 0.1)])
+    ("robotarium_gym:PredatorCapturePrey-v0", {"predator": 3, "capture": 2, "n_agents": 5}, 25, 0.1),
+    ("robotarium_gym:PredatorCapturePrey-v0", {"barrier_solver": "cvxopt"}, 25, 0.25),       # the gymma block of the interior-point kernels
+    ("robotarium_gym:Warehouse-v0", {"barrier_solver": "cvxopt", "n_agents": 6}, 30, 0.1)])
 def test_batched_runner_in_place_path_equals_the_composed_one(key, ov, limit, epsilon, kernel, monkeypatch):
     """BatchedRunner over a fused GymmaVecEnv is TWO launches per time step: the env step writes the next observation (zeros for
     an env that ended: rg_step_io.zero_obs_on_end), the summed reward and the episode-end flags straight into the transition
