@@ -95,6 +95,14 @@ def _configs():
             for cap in (False, True):
                 out.append((f"mt-n{n}-{'cap' if cap else 'plain'}", "MaterialTransport", dict(mt, capability_aware=cap), 20))
     out.append(("arctic", "ArcticTransport", {}, 5))
+    # the interior-point mode's kernels (their own instantiations, LDS workspaces, the gymma and rollout forms): N <= 8
+    ip = {"barrier_solver": "cvxopt"}
+    for n in (2, 5, 8):
+        npred = (n + 1) // 2
+        out.append((f"ipm-pcp-n{n}", "PredatorCapturePrey", dict(ip, predator=npred, capture=n - npred, n_agents=n), 5))
+        out.append((f"ipm-warehouse-n{n}", "Warehouse", dict(ip, n_agents=n), 5))
+    out.append(("ipm-mt-n6", "MaterialTransport", dict(ip, n_agents=6, n_fast_agents=3, n_slow_agents=3, start_dist=0.25), 20))
+    out.append(("ipm-arctic", "ArcticTransport", dict(ip), 5))
     return out
 
 
