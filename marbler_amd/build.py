@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librobogym_hip.so")
 SOURCES = ["robogym_kernels.hip", "robogym_rollout_group.hip", "robogym_kernels_ipm.hip", "robogym_rollout_group_ipm.hip",
            "robogym_tpe.hip", "robogym_rollout_tpe.hip", "robogym_capi.hip", "actor_mfma.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("sim_math.h", "kernel_args.h", "device_common.h", "step_group.h", "step_tpe.h", "step_tpe_ipm.h", "ipm_qp.h", os.path.join("probes", "diag.h"))
+HEADERS = [os.path.join(CSRC, h) for h in ("sim_math.h", "kernel_args.h", "device_common.h", "step_group.h", "step_tpe.h", "step_tpe_ipm.h", "ipm_qp.h", os.path.join("probes", "diag.h"), os.path.join("probes", "actor_diag.h"))
                                            if os.path.exists(os.path.join(CSRC, h))] + \
           [os.path.join(HERE, "..", "include", "robogym.h")]
 ARCH = "gfx950"

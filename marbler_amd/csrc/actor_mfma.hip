@@ -36,6 +36,7 @@
 #include <stdio.h>
 
 #include "../../include/robogym.h"
+#include "probes/actor_diag.h"   // RG_ASTAMP* / RG_AKEEP*: phase stamps of the diagnostic builds, nothing in the shipped one
 
 namespace rg {
 
@@ -117,16 +118,6 @@ __device__ __forceinline__ float relu_(float x) { return x < 0.0f ? 0.0f : x; }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-#ifdef RG_ACTOR_STAMPS  // diagnostic build (tools/actor_stamps.py): wave-cycle stamps of the phases, written over q
-#define RG_ASTAMP(i) stamps[i] = static_cast<int>(__builtin_amdgcn_s_memtime() - t_start)
-#else
-#define RG_ASTAMP(i)
-#endif
-#ifdef RG_ACTOR_STAMPS_FC1   // the head of the wave in detail (slots 2..5; the later phases' stamps are left out)
-#define RG_HSTAMP(i) RG_ASTAMP(i)
-#else
-#define RG_HSTAMP(i)
-#endif
 
 // Two [TM][H] images in LDS with pitch exactly H.  Bank conflicts are avoided by an XOR swizzle of the 16-byte block index
 // with the row instead of padding: block b of row i lives at block b ^ (i & 7).  The eight lanes of an LDS lane group read the
@@ -161,10 +152,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <int H, int SPLIT>   // SPLIT: the GRU's products on 1: three bfloat16 planes (gru_packed == 2), 2: two binary16 planes (gru_packed == 3)
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256 registers (VGPR + AGPR): two tiles per CU, one's serial phases under the other's MFMAs
 __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a) {
-#ifdef RG_ACTOR_STAMPS
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), rt_start = __builtin_amdgcn_s_memrealtime();
-    int stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
+    RG_ASTAMP_BEGIN();
     constexpr int NW = H / 32;  // wavefronts per tile
     constexpr int NTHREADS = 64 * NW;
     // SPLIT == 2: a third image.  Y is then held as its two binary16 planes (in the place of its float32 image: the same size), the
@@ -342,10 +330,8 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             }
         }
     }
-#ifdef RG_ACTOR_STAMPS_FC1
-    asm volatile("" ::"v"(acc), "v"(b1));
+    RG_HKEEP2(acc, b1);
     RG_HSTAMP(4);  // (head) fc1's products and its bias have arrived
-#endif
     __syncthreads();   // every wave is done with the staged operands: their place becomes Y and the old hidden state
     // SPLIT == 2: the head of the GRU's weight stream and its biases are requested HERE, ahead of fc1's epilogue (its conversions,
     // LDS stores and barrier), not behind it: the stream's first trip to L2 runs under the epilogue.
@@ -459,13 +445,9 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 ac[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, ac[ai], 0, 0, 0);
                 am[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, am[ai], 0, 0, 0);
             }
-#ifdef RG_ACTOR_STAMPS
 #pragma unroll
-            for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(am[g]), "v"(ac[g]));
-#ifndef RG_ACTOR_STAMPS_FC1
-            RG_ASTAMP(2);  // GRU products
-#endif
-#endif
+            for (int g = 0; g < 4; ++g) RG_AKEEP2(am[g], ac[g]);
+            RG_PSTAMP(2);  // GRU products
             request_fc2();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -593,13 +575,9 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
                 for (int q4 = 0; q4 < 8; ++q4) wcur[q4] = wnext[q4];
             }
             }  // !SPLIT
-#ifdef RG_ACTOR_STAMPS
 #pragma unroll
-            for (int g = 0; g < 3; ++g) asm volatile("" ::"v"(gi[g]), "v"(gh[g]));
-#ifndef RG_ACTOR_STAMPS_FC1
-            RG_ASTAMP(2);  // GRU products
-#endif
-#endif
+            for (int g = 0; g < 3; ++g) RG_AKEEP2(gi[g], gh[g]);
+            RG_PSTAMP(2);  // GRU products
             if constexpr (SPLIT != 1) request_biases();
             request_fc2();
 #pragma unroll
@@ -629,13 +607,9 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             for (int r = 0; r < 16; ++r) hn[r] = relu_(acc[r] + b);
         }
     }
-#ifdef RG_ACTOR_STAMPS
 #pragma unroll
-    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(hn[r]));
-#ifndef RG_ACTOR_STAMPS_FC1
-    RG_ASTAMP(3);  // gates
-#endif
-#endif
+    for (int r = 0; r < 16; ++r) RG_AKEEP1(hn[r]);
+    RG_PSTAMP(3);  // gates
     // The new hidden state goes out to memory NOW, from the accumulator layout (per register: two rows x 128 contiguous bytes per
     // wave), and drains under fc2 and the arg-max.  The barriers from here on order LDS only (lds_barrier): __syncthreads would
     // wait for these stores at every one of them -- which is why, until round 5, they were issued at the very end, where all 512
@@ -658,9 +632,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         }
     }
     lds_barrier();
-#ifndef RG_ACTOR_STAMPS_FC1
-    RG_ASTAMP(4);  // new hidden state in LDS
-#endif
+    RG_PSTAMP(4);  // new hidden state in LDS
 
     // ---- fc2: q = h' W2^T + b2 (A <= 32 columns: one 32 x 32 tile).  The K range is split over the tile's wavefronts --
     // 32 k values = 16 MFMAs each instead of H / 2 on one wavefront while the others wait -- and the partial tiles meet in LDS.
@@ -675,9 +647,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
         for (int r = 0; r < 16; ++r) Y[cb * (TM * 32) + crow(r) * 32 + col] = acc[r];  // Y is free again: NW partial tiles, row-major
     }
     lds_barrier();
-#ifndef RG_ACTOR_STAMPS_FC1
-    RG_ASTAMP(5);  // fc2 partial products
-#endif
+    RG_PSTAMP(5);  // fc2 partial products
     {   // every thread: TPR threads per tile row, CPT action columns each; then the greedy action of the row
         const int i = tid / TPR, sub = tid % TPR;
         const bool ok = row_ok(i);
@@ -720,17 +690,7 @@ __global__ __launch_bounds__(64 * (H / 32)) void actor_kernel(const ActorArgs a)
             a.actions[r] = arg;
         }
     }
-#ifdef RG_ACTOR_STAMPS
-    RG_ASTAMP(6);
-    stamps[7] = static_cast<int>(__builtin_amdgcn_s_memrealtime() - rt_start);   // the wave's life on the constant 100 MHz clock: slot 6 / slot 7 = shader clock / 100 MHz
-    // slot 0: where the wave ran -- XCC_ID (hwreg 20) << 16 | HW_ID (hwreg 4: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
-    stamps[0] = static_cast<int>((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 16) | (__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xFFFF));
-    __syncthreads();
-    if (lane == 0 && a.q) {
-        int *dst = reinterpret_cast<int *>(a.q) + static_cast<size_t>(E) * N * A + (static_cast<size_t>(blockIdx.x) * (H / 32) + cb) * 8;  // behind the q block
-        for (int i = 0; i < 8; ++i) dst[i] = stamps[i];
-    }
-#endif
+    RG_ASTAMP_END(a, E, N, A, H, cb, lane);
 }
 
 // torch layout [S][3H][H] -> the kernel's streaming order [S][cb][chunk][gate][q4][lane = (half, col)][4]
@@ -852,14 +812,7 @@ extern "C" int rg_actor_pack_gru(const float *src, int32_t n_sets, int32_t hidde
 
 extern "C" const char *rg_actor_last_error(void) { return g_actor_err; }
 
-#ifdef RG_ACTOR_STAMPS  // diagnostic build: what the runtime says about co-resident workgroups per CU
-extern "C" int rg_actor_occupancy(int hidden_dim) {
-    int n = -1;
-    if (hidden_dim == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<64, 1>, 128, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rg::actor_kernel<128, 1>, 256, 0);
-    return n;
-}
-#endif
+RG_ACTOR_DIAG_ENTRY   // (diagnostic builds: rg_actor_occupancy)
 
 static int actor_forward(const rg_actor_weights *w, int32_t num_envs, int32_t n_agents, const float *obs,
                          int32_t obs_dim, int32_t append_agent_id, const uint8_t *restart, float *hidden,
